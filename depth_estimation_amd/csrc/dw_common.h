@@ -1,0 +1,56 @@
+// Shared device helpers for libdepthwarp (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "depthwarp.h"
+
+namespace dw {
+
+// Constants of the forward definition, as the float32 values nearest to the
+// decimal ones (written as hex floats so host and device agree to the bit).
+constexpr float kNinth = 0x1.c71c72p-4f;      // fl(1/9)
+constexpr float kThird = 0x1.555556p-2f;      // fl(1/3)
+constexpr float kC1 = 0x1.a36e2ep-14f;        // fl(0.01^2)
+constexpr float kC2 = 0x1.d7dbf4p-11f;        // fl(0.03^2)
+constexpr float kWSsim = 0x1.b33334p-1f;      // fl(0.85)
+constexpr float kWL1 = 0x1.333334p-3f;        // fl(0.15)
+constexpr float kMinDisp = 0x1.47ae14p-7f;    // fl(1/100)
+constexpr float kDispRange = 0x1.3fae14p+3f;  // fl(1/0.1 - 1/100)
+constexpr float kProjEps = 0x1.ad7f2ap-24f;   // fl(1e-7)
+constexpr float kMeanEps = 1e-7f;
+constexpr float kWSmooth = 1e-3f;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Sum over the block, in a fixed order (bitwise reproducible). The result is
+// valid in thread 0. `red` holds NT/64 floats. Contains two barriers.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / kWave; ++i) t += red[i];
+  }
+  return t;
+}
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return min(max(i, 0), n - 1);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace dw

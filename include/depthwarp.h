@@ -1,0 +1,139 @@
+/*
+ * depthwarp.h -- C ABI of libdepthwarp.so (MI355X / gfx950).
+ *
+ * Hand-written HIP kernels for the view-synthesis + photometric-loss path of
+ * self-supervised depth training, and for the one loss function the reference
+ * holds (Train.compute_loss, /root/reference/train.py:272-309).
+ *
+ * Conventions (every entry point):
+ *   - every data pointer is a DEVICE pointer owned by the caller; arrays of
+ *     pointers ("const float* const* disp") are HOST arrays of device pointers;
+ *   - tensors are contiguous NCHW float32 unless stated otherwise;
+ *   - nothing is allocated, freed or synchronised inside a call: all launches
+ *     are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream); scratch memory comes from the caller's `workspace`;
+ *   - calls are stateless and re-entrant (two calls may overlap if their
+ *     workspaces and outputs do not);
+ *   - the return value is DW_OK (0) or a negative DW_ERR_* code; nothing is
+ *     thrown across the boundary; dw_strerror() names a code.
+ *
+ * The reference has no FFI of its own: each declaration cites the Python
+ * call it stands behind (reference file:line), or says that the stage is
+ * absent from the reference.
+ */
+#ifndef DEPTHWARP_H
+#define DEPTHWARP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(DW_BUILD)
+#define DW_API __attribute__((visibility("default")))
+#else
+#define DW_API
+#endif
+
+#define DW_VERSION 1
+#define DW_MAX_SCALES 4
+#define DW_NUM_SRC 2
+
+enum {
+  DW_OK = 0,
+  DW_ERR_NULL = -1,      /* a required pointer is NULL                         */
+  DW_ERR_SHAPE = -2,     /* unsupported or inconsistent dimensions             */
+  DW_ERR_WORKSPACE = -3, /* workspace too small or misaligned                  */
+  DW_ERR_LAUNCH = -4,    /* hipLaunchKernel / hipGetLastError reported failure */
+  DW_ERR_ARG = -5        /* bad flag or enum value                             */
+};
+
+/* Problem description of the photometric stack. Scale s has H>>s x W>>s
+ * pixels; H and W must be divisible by 2^(S-1); F must be DW_NUM_SRC. */
+typedef struct dw_desc {
+  int32_t B; /* samples (3-frame sequences)                 */
+  int32_t H; /* full-resolution height                      */
+  int32_t W; /* full-resolution width                       */
+  int32_t S; /* scales, 1..DW_MAX_SCALES                    */
+  int32_t F; /* source frames, = DW_NUM_SRC                 */
+  int32_t flags; /* reserved, 0                             */
+} dw_desc;
+
+DW_API int dw_version(void);
+DW_API const char* dw_strerror(int code);
+
+/* ---------------------------------------------------------------------------
+ * Fused photometric stack (stages absent from the reference; they follow the
+ * networks at /root/reference/train.py:111 and replace the loss call at
+ * train.py:113 in a self-supervised set-up).
+ *
+ * Forward, per scale s: bilinear up-sample of disp[s] -> depth -> back-project
+ * with inv_K -> project with (K @ T[f])[:3] -> bilinear border warp of
+ * color[1+f] -> 0.85*SSIM(3x3, reflect) + 0.15*L1 against color[0]; identity
+ * errors of the un-warped sources (+ tie_noise); per-pixel minimum over
+ * [id0, id1, reproj0, reproj1]; mean; plus 1e-3/2^s * edge-aware smoothness of
+ * the mean-normalised disp[s] against color_pyr[s]; averaged over scales.
+ *
+ *   disp[s]       (B,1,H>>s,W>>s)            s < S
+ *   color[0..2]   (B,3,H,W)   target, source(-1), source(+1)
+ *   color_pyr[s]  (B,3,H>>s,W>>s)  target colour per scale ([0] may alias color[0])
+ *   K, inv_K      (B,4,4)  pixel-unit intrinsics
+ *   T             (B,F,4,4)  target->source rigid transforms
+ *   tie_noise     (B,F,H,W) or NULL
+ *   mask[s]       (B,H,W) uint8 out: bits 0-1 arg-min index (0,1 identity;
+ *                 2,3 re-projection), bit 2 / 3 validity of source 0 / 1.
+ *                 An entry (or the array) may be NULL to skip the store.
+ *   loss_out      1 + 2*S floats out: total, L_photo[0..S), L_sm[0..S)
+ *   with_grad     non-zero: also stash in `workspace` what dw_photometric_bwd
+ *                 needs (the pass is then forward + the heavy part of backward)
+ * ------------------------------------------------------------------------- */
+DW_API size_t dw_photometric_workspace_bytes(const dw_desc* desc);
+
+DW_API int dw_photometric_fwd(const dw_desc* desc,
+                       const float* const* disp,
+                       const float* const* color,
+                       const float* const* color_pyr,
+                       const float* K, const float* inv_K, const float* T,
+                       const float* tie_noise,
+                       uint8_t* const* mask,
+                       float* loss_out,
+                       void* workspace, size_t workspace_bytes,
+                       int with_grad, void* stream);
+
+/* Backward of the call above (same desc, same workspace, untouched since).
+ *   grad_loss     device scalar: upstream gradient of the total loss
+ *   grad_disp[s]  (B,1,H>>s,W>>s) out (overwritten)
+ *   grad_T        (B,F,4,4) out (overwritten); may be NULL
+ */
+DW_API int dw_photometric_bwd(const dw_desc* desc,
+                       const float* const* disp,
+                       const float* K,
+                       const float* grad_loss,
+                       const void* workspace, size_t workspace_bytes,
+                       float* const* grad_disp,
+                       float* grad_T,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Reference loss: Train.compute_loss(target, pred), train.py:272-309, forward
+ * only as in the reference (its body runs under no_grad, train.py:274).
+ * Batched: sample b of the result equals the reference's batch-1 call on
+ * sample b.
+ *   target   (B,1,Ht,Wt)  ground truth, resized to (H,W) inside (bilinear,
+ *            align_corners=False, no antialias; train.py:276)
+ *   pred     (B,1,H,W)
+ *   out      (B,4) floats: loss, ssim_term, l1, smooth   (train.py:299-307)
+ *   workspace: dw_compute_loss_workspace_bytes(B,H,W) bytes
+ * ------------------------------------------------------------------------- */
+DW_API size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
+
+DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                        const float* target, const float* pred, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPTHWARP_H */
