@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: warp + photometric-loss forward/backward throughput.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one fused forward (with gradient stash) + one backward of the
+view-synthesis / photometric-loss stack over one synthetic batch of 3-frame
+sequences: B=12 per GPU, 192x640, 2 source frames, 4 scales.  Inputs are
+resident in HBM before the timed region.  For N > 1 the driver launches one
+rank per GPU (torch.distributed.run); each rank processes its own batch shard
+(weak scaling; the op itself needs no exchange) and the slowest rank sets the
+time.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=12, help="sequences per GPU")
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-graph", action="store_true", help="issue launches eagerly, no HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="sequences in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a port: the reference holds no implementation of these
+    stages) timed on this host, forward + backward, on a bounded sample."""
+    from depth_estimation_amd.synth import make_sequence
+    from oracle import photometric as ph
+    B = args.cpu_batch
+    seq = make_sequence(B, args.height, args.width, seed=0)
+    cores = torch.get_num_threads()
+
+    def step():
+        disp = [d.clone().requires_grad_(True) for d in seq.disp]
+        T = seq.T.clone().requires_grad_(True)
+        loss = ph.photometric_stack(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T)
+        loss.backward()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 3 and (el > 10.0 or n >= 10):
+            break
+        if el > 25.0:
+            break
+    per = el / n
+    return {"value": 3 * B / per, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of B={B} at {args.height}x{args.width}, 2 sources, "
+                      f"4 scales, float32, torch CPU threads={cores}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from depth_estimation_amd.synth import make_sequence, algorithmic_bytes
+    from depth_estimation_amd.ops import PhotometricPlan
+    from depth_estimation_amd._lib import lib
+
+    B, H, W, S = args.batch, args.height, args.width, 4
+    seq = make_sequence(B, H, W, S=S, seed=rank).to(dev)
+    plan = PhotometricPlan(B, H, W, S, dev).bind(*seq.args())
+
+    def step():
+        plan.forward(with_grad=True)
+        plan.backward()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
+    else:
+        run = step
+
+    for _ in range(args.warmup):
+        run()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(plan.loss[0].item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    frames = 3 * B * world
+    value = frames / (elapsed / args.steps)
+    alg = algorithmic_bytes(B, H, W, S)
+
+    out = {
+        "metric": "warp+photometric-loss fwd+bwd throughput",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"warp+SSIM/L1+smoothness fwd/bwd microbench, {H}x{W}, "
+                               f"batch={B}/GPU, 2 source frames, 4 scales",
+                   "global_batch": B * world, "launch": "eager" if graph is None else "hip-graph"},
+        "hbm_gbps_algorithmic": world * alg["total"] / (elapsed / args.steps) / 1e9,
+        "loss": loss_val,
+    }
+
+    if rank == 0 and world == 1:
+        # Dominant kernel alone (the per-tile fused kernel), HIP events on the
+        # stream it is launched on.
+        from depth_estimation_amd._lib import DwDesc
+        tile_plan = PhotometricPlan(B, H, W, S, dev, flags=1).bind(*seq.args())
+        for _ in range(10):
+            tile_plan.forward(with_grad=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(20, min(args.steps, 200))
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            tile_plan.forward(with_grad=True)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / reps
+        achieved = alg["total"] / (k_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "photo_tile_kernel<true>",
+                           "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                           "kernel_ms": k_ms, "algorithmic_bytes": alg["total"]}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

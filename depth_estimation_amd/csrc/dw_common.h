@@ -51,6 +51,25 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
   return min(max(i, 0), n - 1);
 }
 
+
+struct Taps {
+  int i0, i1;
+  float l0, l1;
+};
+
+// Source taps of the bilinear up-sampling (align_corners = false):
+// src = (dst + 0.5) * (in / out) - 0.5, clamped at 0.
+__device__ __forceinline__ Taps upsample_taps(int dst, int in_size, float scale) {
+  Taps t;
+  float src = ((float)dst + 0.5f) * scale - 0.5f;
+  src = fmaxf(src, 0.f);
+  t.i0 = (int)src;
+  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace dw

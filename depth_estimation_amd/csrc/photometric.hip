@@ -58,24 +58,6 @@ struct PhotoParams {
 };
 
 // ------------------------------------------------------------------ geometry
-struct Taps {
-  int i0, i1;
-  float l0, l1;
-};
-
-// Source taps of the bilinear up-sampling (align_corners = false):
-// src = (dst + 0.5) * (in / out) - 0.5, clamped at 0.
-__device__ __forceinline__ Taps upsample_taps(int dst, int in_size, float scale) {
-  Taps t;
-  float src = ((float)dst + 0.5f) * scale - 0.5f;
-  src = fmaxf(src, 0.f);
-  t.i0 = (int)src;
-  t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
-  t.l1 = src - (float)t.i0;
-  t.l0 = 1.0f - t.l1;
-  return t;
-}
-
 __device__ __forceinline__ float upsampled_disp(const float* __restrict__ d, int hs, int ws,
                                                 int s, int y, int x, float sy, float sx) {
   if (s == 0) return d[(long)y * ws + x];
@@ -778,6 +760,7 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, int& tile
 static int check_desc(const dw_desc* d) {
   if (!d) return DW_ERR_NULL;
   if (d->B < 1 || d->S < 1 || d->S > DW_MAX_SCALES || d->F != DW_NUM_SRC) return DW_ERR_SHAPE;
+  if (d->flags & ~DW_FLAG_TILE_KERNEL_ONLY) return DW_ERR_ARG;
   const int m = 1 << (d->S - 1);
   if (d->H % m || d->W % m) return DW_ERR_SHAPE;
   if ((d->H >> (d->S - 1)) < 2 || (d->W >> (d->S - 1)) < 2) return DW_ERR_SHAPE;
@@ -839,8 +822,15 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
 
-  disp_mean_kernel<<<dim3(p.B, p.S), 1024, 0, st>>>(p);
   const dim3 tgrid(p.tilesX * p.tilesY, p.B);
+  if (desc->flags & DW_FLAG_TILE_KERNEL_ONLY) {
+    if (with_grad)
+      photo_tile_kernel<true><<<tgrid, NT, 0, st>>>(p);
+    else
+      photo_tile_kernel<false><<<tgrid, NT, 0, st>>>(p);
+    return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
+  }
+  disp_mean_kernel<<<dim3(p.B, p.S), 1024, 0, st>>>(p);
   if (with_grad) {
     photo_tile_kernel<true><<<tgrid, NT, 0, st>>>(p);
     smooth_kernel<true><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);

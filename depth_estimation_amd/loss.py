@@ -1,0 +1,79 @@
+"""`compute_loss(target, pred)`: the reference's loss function as one HIP call.
+
+Mirrors `Train.compute_loss(self, target, pred)` at
+/root/reference/train.py:272-309 (`self` is unused there): SSIM(7x7) + L1 + a
+Sobel term on the resized ground truth, mixed 0.75 / 0.20 / 0.15, computed
+without gradient exactly as in the reference (its body runs under `no_grad`,
+train.py:274; the caller marks the scalar `requires_grad_` itself, train.py:114).
+
+The reference is hard-wired to batch 1 (`view(1, 1, H, W)`, train.py:277-279).
+Here a batch is allowed: sample b of the result equals the reference call on
+sample b; a batch of one returns a 0-dim tensor like the reference.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+__all__ = ["compute_loss", "compute_loss_terms"]
+
+
+def _as_b1hw(name: str, t: Tensor) -> Tensor:
+    if t.dim() == 3:
+        t = t[:, None]
+    if t.dim() != 4 or t.shape[1] != 1:
+        raise RuntimeError(f"{name}: expected (B,H,W) or (B,1,H,W), got {tuple(t.shape)}")
+    return t
+
+
+@torch.library.custom_op("depthwarp::compute_loss_fwd", mutates_args=())
+def compute_loss_fwd(target: Tensor, pred: Tensor) -> Tensor:
+    """target (B,1,Ht,Wt), pred (B,1,H,W), float32 -> (B,4): loss, ssim_term, l1, smooth."""
+    if not (target.is_cuda and pred.is_cuda):
+        raise _lib.DepthwarpError("compute_loss: expected ROCm device tensors "
+                                  "(the HIP kernels have no CPU path)")
+    B, _, H, W = pred.shape
+    if target.shape[0] != B:
+        raise RuntimeError("compute_loss: target and pred disagree on the batch size")
+    target = target.contiguous()
+    pred = pred.contiguous()
+    lib = _lib.lib()
+    nbytes = lib.dw_compute_loss_workspace_bytes(B, H, W)
+    if nbytes == 0:
+        raise _lib.DepthwarpError(f"compute_loss: unsupported shape B={B} H={H} W={W}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+    out = torch.empty((B, 4), dtype=torch.float32, device=pred.device)
+    with torch.cuda.device(pred.device):
+        rc = lib.dw_compute_loss_fwd(B, target.shape[2], target.shape[3], H, W,
+                                     target.data_ptr(), pred.data_ptr(), out.data_ptr(),
+                                     ws.data_ptr(), nbytes,
+                                     torch.cuda.current_stream(pred.device).cuda_stream)
+    _lib.check(rc, "dw_compute_loss_fwd")
+    return out
+
+
+@compute_loss_fwd.register_fake
+def _(target, pred):
+    return torch.empty((pred.shape[0], 4), dtype=torch.float32, device=pred.device)
+
+
+def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: int = None):
+    """Per-sample terms as a dict of (B,) tensors: loss, ssim_term, l1, smooth."""
+    with torch.no_grad():
+        pred = _as_b1hw("pred", pred)
+        target = _as_b1hw("target", target)
+        if height is not None and tuple(pred.shape[-2:]) != (height, width):
+            # the reference's `pred.view(1, 1, H, W)` raises on a size mismatch
+            raise RuntimeError(f"pred has shape {tuple(pred.shape)}, expected (*,1,{height},{width})")
+        # the reference hands over a float64 target (NumPy pipeline); compute in float32
+        out = compute_loss_fwd(target.float(), pred.float())
+    return {"loss": out[:, 0], "ssim_term": out[:, 1], "l1": out[:, 2], "smooth": out[:, 3]}
+
+
+def compute_loss(target: Tensor, pred: Tensor, height: int = None, width: int = None) -> Tensor:
+    """Drop-in for `Train.compute_loss(target, pred)`; the output size is
+    `pred`'s (the reference reads it from `Config.height/width`)."""
+    loss = compute_loss_terms(target, pred, height, width)["loss"]
+    return loss[0] if loss.numel() == 1 else loss

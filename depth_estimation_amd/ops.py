@@ -177,3 +177,56 @@ def photometric_forward(disp, color, color_pyr, K, inv_K, T, tie_noise=None):
 def photometric_stack(disp, color, color_pyr, K, inv_K, T, tie_noise=None) -> Tensor:
     """Scalar multi-scale view-synthesis loss (differentiable w.r.t. disp and T)."""
     return photometric_forward(disp, color, color_pyr, K, inv_K, T, tie_noise)[0][0]
+
+
+class PhotometricPlan:
+    """Pre-allocated buffers + raw C-ABI calls for one problem shape.
+
+    Nothing is allocated per call, so a step (forward + backward) can be
+    replayed from a HIP graph or issued back to back from a tight loop.  The
+    autograd path above allocates its outputs per call instead; both run the
+    same kernels.
+    """
+
+    def __init__(self, B: int, H: int, W: int, S: int = 4, device="cuda", flags: int = 0):
+        self.desc = DwDesc(B, H, W, S, DW_NUM_SRC, flags)
+        self.device = torch.device(device)
+        self.nbytes = workspace_bytes(B, H, W, S)
+        dev = self.device
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        self.loss = torch.zeros(1 + 2 * S, dtype=torch.float32, device=dev)
+        self.mask = torch.empty((S, B, H, W), dtype=torch.uint8, device=dev)
+        self.grad_disp = [torch.empty((B, 1, H >> s, W >> s), dtype=torch.float32, device=dev)
+                          for s in range(S)]
+        self.grad_T = torch.empty((B, DW_NUM_SRC, 4, 4), dtype=torch.float32, device=dev)
+        self.one = torch.ones(1, dtype=torch.float32, device=dev)
+        self._mask_ptrs = _lib.ptr_array([self.mask[s] for s in range(S)])
+        self._gd_ptrs = _lib.ptr_array(self.grad_disp)
+        self._lib = _lib.lib()
+
+    def bind(self, disp, color, color_pyr, K, inv_K, T, tie_noise=None):
+        """Validate once and keep the pointer arrays of a fixed set of inputs."""
+        _validate(disp, color, color_pyr, K, inv_K, T, tie_noise)
+        self._in = (list(disp), list(color), list(color_pyr), K, inv_K, T, tie_noise)
+        self._p = (_lib.ptr_array(disp), _lib.ptr_array(color), _lib.ptr_array(color_pyr),
+                   K.data_ptr(), inv_K.data_ptr(), T.data_ptr(),
+                   None if tie_noise is None else tie_noise.data_ptr())
+        return self
+
+    def forward(self, with_grad: bool = True, stream: Optional[int] = None):
+        d, c, py, K, iK, T, tie = self._p
+        rc = self._lib.dw_photometric_fwd(self.desc, d, c, py, K, iK, T, tie, self._mask_ptrs,
+                                          self.loss.data_ptr(), self.ws.data_ptr(), self.nbytes,
+                                          1 if with_grad else 0,
+                                          _stream(self.device) if stream is None else stream)
+        _lib.check(rc, "dw_photometric_fwd")
+        return self.loss
+
+    def backward(self, grad_loss: Optional[Tensor] = None, stream: Optional[int] = None):
+        g = self.one if grad_loss is None else grad_loss
+        rc = self._lib.dw_photometric_bwd(self.desc, self._p[0], self._p[3], g.data_ptr(),
+                                          self.ws.data_ptr(), self.nbytes, self._gd_ptrs,
+                                          self.grad_T.data_ptr(),
+                                          _stream(self.device) if stream is None else stream)
+        _lib.check(rc, "dw_photometric_bwd")
+        return self.grad_disp, self.grad_T

@@ -58,8 +58,13 @@ typedef struct dw_desc {
   int32_t W; /* full-resolution width                       */
   int32_t S; /* scales, 1..DW_MAX_SCALES                    */
   int32_t F; /* source frames, = DW_NUM_SRC                 */
-  int32_t flags; /* reserved, 0                             */
+  int32_t flags; /* 0, or DW_FLAG_* for profiling runs       */
 } dw_desc;
+
+/* Profiling only: dw_photometric_fwd launches just its dominant kernel (the
+ * per-tile warp/error/adjoint kernel); outputs other than the masks are then
+ * not produced. Used to time that kernel alone with events. */
+#define DW_FLAG_TILE_KERNEL_ONLY 1
 
 DW_API int dw_version(void);
 DW_API const char* dw_strerror(int code);

@@ -77,8 +77,8 @@ def test_upstream_gradient_scales():
     _, _, gd1, gT1 = _hip(seq, 1.0)
     _, _, gd2, gT2 = _hip(seq, -2.5)
     for a, b in zip(gd1, gd2):
-        assert torch.allclose(a * -2.5, b, rtol=1e-6, atol=0)
-    assert torch.allclose(gT1 * -2.5, gT2, rtol=1e-6, atol=0)
+        assert _rel(a * -2.5, b) <= 1e-5
+    assert _rel(gT1 * -2.5, gT2) <= 1e-5
 
 
 def test_bitwise_reproducible():
