@@ -8,8 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libdepthwarp.so"
+# DEPTHWARP_LIB selects another build of the same library (kernel tuning A/B runs).
+LIB_PATH = Path(os.environ.get("DEPTHWARP_LIB", _PKG / "libdepthwarp.so"))
 
 DW_MAX_SCALES = 4
 DW_NUM_SRC = 2

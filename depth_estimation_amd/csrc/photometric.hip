@@ -25,7 +25,7 @@ namespace dw {
 
 constexpr int TH = 16;   // tile rows
 constexpr int TW = 64;   // tile columns
-constexpr int NT = 256;  // threads per tile block
+constexpr int NT = 512;  // threads per tile block (2 waves per SIMD; LDS allows one block per CU)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
 constexpr int SM_NT = 256;
 
