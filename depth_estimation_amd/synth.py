@@ -6,7 +6,11 @@ are shifted copies of the target plus noise, sigmoid-of-noise disparities at
 four scales, the KITTI-style intrinsics the reference carries at
 `/root/reference/dataset/load_dataset.py:21-24` (normalised, scaled to pixels
 here), and small random rigid motions.  Everything is generated on the CPU from
-one `torch.Generator` so that a GPU run and a CPU run see identical bits.
+one `torch.Generator` so that a GPU run and a CPU run see identical bits, and
+only from uniform random numbers and correctly rounded IEEE operations (add,
+mul, div, sqrt, abs): no libm or vectorised transcendental is involved, so two
+hosts with different CPUs produce the same inputs and the committed golden
+outputs stay valid on both.
 """
 from __future__ import annotations
 
@@ -50,7 +54,10 @@ def intrinsics(B: int, H: int, W: int, dtype=torch.float32):
     K = torch.tensor(K_NORM, dtype=torch.float64)
     K[0] *= W
     K[1] *= H
-    inv_K = torch.linalg.inv(K)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    inv_K = torch.eye(4, dtype=torch.float64)
+    inv_K[0, 0], inv_K[0, 2] = 1.0 / fx, -cx / fx
+    inv_K[1, 1], inv_K[1, 2] = 1.0 / fy, -cy / fy
     return (K.to(dtype)[None].repeat(B, 1, 1).contiguous(),
             inv_K.to(dtype)[None].repeat(B, 1, 1).contiguous())
 
@@ -84,8 +91,33 @@ def pose_to_matrix(axisangle: torch.Tensor, translation: torch.Tensor,
 
 
 def _box(x, k):
+    """k x k mean with replicate border, as explicit shifted adds (fixed order)."""
     pad = k // 2
-    return F.avg_pool2d(F.pad(x, (pad, pad, pad, pad), mode="replicate"), k, 1)
+    p = F.pad(x, (pad, pad, pad, pad), mode="replicate")
+    H, W = x.shape[-2:]
+    acc = torch.zeros_like(x)
+    for dy in range(k):
+        for dx in range(k):
+            acc = acc + p[..., dy:dy + H, dx:dx + W]
+    return acc / float(k * k)
+
+
+def _down2(x):
+    return ((x[..., 0::2, 0::2] + x[..., 0::2, 1::2]) + (x[..., 1::2, 0::2] + x[..., 1::2, 1::2])) / 4.0
+
+
+def _small_rotation(vec: torch.Tensor) -> torch.Tensor:
+    """Rodrigues formula with the sine / cosine of the (small) angle taken from
+    their Taylor polynomials, so that only exact IEEE operations are used."""
+    a2 = (vec * vec).sum(1, keepdim=True)
+    sinc = 1 - a2 / 6 + a2 * a2 / 120          # sin(a) / a
+    cosc = 0.5 - a2 / 24 + a2 * a2 / 720       # (1 - cos(a)) / a^2
+    x, y, z = vec[:, 0:1], vec[:, 1:2], vec[:, 2:3]
+    ca = 1 - a2 * cosc
+    rows = [torch.cat([x * x * cosc + ca, x * y * cosc - z * sinc, x * z * cosc + y * sinc], 1),
+            torch.cat([x * y * cosc + z * sinc, y * y * cosc + ca, y * z * cosc - x * sinc], 1),
+            torch.cat([x * z * cosc - y * sinc, y * z * cosc + x * sinc, z * z * cosc + ca], 1)]
+    return torch.stack(rows, 1)
 
 
 def make_sequence(B: int, H: int, W: int, S: int = 4, seed: int = 0,
@@ -93,7 +125,13 @@ def make_sequence(B: int, H: int, W: int, S: int = 4, seed: int = 0,
     assert H % (1 << (S - 1)) == 0 and W % (1 << (S - 1)) == 0
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *shape: torch.rand(*shape, generator=g, dtype=torch.float64)
-    rndn = lambda *shape: torch.randn(*shape, generator=g, dtype=torch.float64)
+
+    def rndn(*shape):  # ~N(0,1): centred sum of four uniforms, exact operations only
+        u = ((rnd(*shape) + rnd(*shape)) + (rnd(*shape) + rnd(*shape))) - 2.0
+        return u * 1.7320508075688772
+
+    def squash(x):  # (0,1)-valued, sigmoid-like, rational
+        return 0.5 + 0.5 * x / (1.0 + x.abs())
 
     tgt = _box(rnd(B, 3, H, W), 5)
     lo = tgt.amin(dim=(1, 2, 3), keepdim=True)
@@ -109,12 +147,12 @@ def make_sequence(B: int, H: int, W: int, S: int = 4, seed: int = 0,
         color.append(src.clamp(0, 1))
     pyr = [color[0]]
     for s in range(1, S):
-        pyr.append(F.avg_pool2d(pyr[-1], 2))
+        pyr.append(_down2(pyr[-1]))
 
     disp = []
     for s in range(S):
         h, w = H >> s, W >> s
-        disp.append(0.02 + 0.06 * _box(torch.sigmoid(rndn(B, 1, h, w)), 3))
+        disp.append(0.02 + 0.06 * _box(squash(rndn(B, 1, h, w)), 3))
 
     K, inv_K = intrinsics(B, H, W, dtype=torch.float64)
     Ts = []
@@ -128,7 +166,11 @@ def make_sequence(B: int, H: int, W: int, S: int = 4, seed: int = 0,
         tr = 0.004 * rndn(B, 3)
         tr[:, 0] += -dx * 3.0 / fx
         tr[:, 1] += -dy * 3.0 / fy
-        Ts.append(pose_to_matrix(aa, tr))
+        Tf = torch.zeros(B, 4, 4, dtype=torch.float64)
+        Tf[:, :3, :3] = _small_rotation(aa)
+        Tf[:, :3, 3] = tr
+        Tf[:, 3, 3] = 1.0
+        Ts.append(Tf)
     T = torch.stack(Ts, 1)
     noise = 1e-5 * rndn(B, 2, H, W) if tie_noise else None
 

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Writes the golden fixtures in this directory from the CPU oracle.
+
+    python tests/golden/make_golden.py
+
+The reference (/root/reference) holds no tests, fixtures or golden vectors and
+cannot be imported here (torchvision, kornia, cv2, skimage, tensorboardX are
+absent; its model constructor fetches weights over the network), so these
+vectors pin the build-owned oracle against drift; they do not pin it to the
+reference ("parity unpinned").  Inputs are regenerated from the seeds with
+`depth_estimation_amd.synth.make_sequence`; only expected outputs are stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from depth_estimation_amd.synth import make_sequence  # noqa: E402
+from oracle import photometric as ph  # noqa: E402
+from oracle import compute_loss as cl  # noqa: E402
+
+PHOTO_CASES = [dict(B=2, H=24, W=80, seed=0, tie=False), dict(B=2, H=48, W=160, seed=0, tie=False),
+               dict(B=1, H=32, W=96, seed=5, tie=True)]
+CL_CASES = [dict(B=1, Ht=375, Wt=1242, H=64, W=128, seed=0), dict(B=1, Ht=375, Wt=1242, H=256, W=512, seed=1),
+            dict(B=2, Ht=64, Wt=128, H=64, W=128, seed=2), dict(B=1, Ht=100, Wt=300, H=48, W=160, seed=3)]
+
+
+def photo_case(c):
+    seq = make_sequence(c["B"], c["H"], c["W"], seed=c["seed"], tie_noise=c["tie"])
+    disp = [d.clone().requires_grad_(True) for d in seq.disp]
+    T = seq.T.clone().requires_grad_(True)
+    loss, aux = ph.photometric_stack(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T,
+                                     seq.tie_noise, return_aux=True)
+    loss.backward()
+    out = {"loss": loss.detach().numpy(), "grad_T": T.grad.numpy(),
+           "checksum_inputs": np.float64(sum(float(t.double().sum()) for t in seq.disp + seq.color))}
+    for s in range(len(disp)):
+        out[f"L_photo{s}"] = aux["L_photo"][s].numpy()
+        out[f"L_sm{s}"] = aux["L_sm"][s].numpy()
+        out[f"mask{s}"] = ph.pack_mask(aux["idx"][s], aux["valid"][s]).numpy()
+        out[f"grad_disp{s}"] = disp[s].grad.numpy()
+        out[f"min_gap{s}"] = np.float32(aux["gap"][s].min())
+    return out
+
+
+def cl_inputs(c):
+    g = torch.Generator().manual_seed(c["seed"])
+    target = torch.rand(c["B"], c["Ht"], c["Wt"], generator=g)
+    pred = torch.rand(c["B"], c["H"], c["W"], generator=g)
+    return target, pred
+
+
+def main():
+    for c in PHOTO_CASES:
+        name = f"photo_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}{'_tie' if c['tie'] else ''}.npz"
+        np.savez_compressed(os.path.join(HERE, name), **photo_case(c))
+        print("wrote", name)
+    rows = {}
+    for i, c in enumerate(CL_CASES):
+        t, p = cl_inputs(c)
+        terms = cl.compute_loss_terms(t, p)
+        rows[f"case{i}"] = np.stack([terms[k].numpy() for k in ("loss", "ssim_term", "l1", "smooth")], 1)
+    np.savez_compressed(os.path.join(HERE, "compute_loss.npz"), **rows)
+    print("wrote compute_loss.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -51,3 +51,16 @@ def test_shape_mismatch_raises():
     from depth_estimation_amd.loss import compute_loss
     with pytest.raises(RuntimeError):
         compute_loss(torch.rand(1, 32, 32).cuda(), torch.rand(1, 32, 32).cuda(), 64, 64)
+
+
+def test_hip_matches_committed_golden_vectors():
+    import os
+    import numpy as np
+    from depth_estimation_amd.loss import compute_loss_terms
+    from tests.golden.make_golden import CL_CASES, cl_inputs
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "compute_loss.npz"))
+    for i, c in enumerate(CL_CASES):
+        t, p = cl_inputs(c)
+        terms = compute_loss_terms(t.cuda(), p.cuda())
+        got = np.stack([terms[k].cpu().numpy() for k in ("loss", "ssim_term", "l1", "smooth")], 1)
+        assert np.allclose(got, gold[f"case{i}"], rtol=RTOL, atol=0), (i, got, gold[f"case{i}"])
