@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not stale():
         return LIB
     srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
-    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off",
+    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
            "-fPIC", "-shared", "-fvisibility=hidden", "-DDW_BUILD",
            f"-I{ROOT / 'include'}", f"-I{CSRC}", *srcs, "-o", str(LIB)]
     if verbose:

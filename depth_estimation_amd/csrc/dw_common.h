@@ -22,11 +22,23 @@ constexpr float kWSmooth = 1e-3f;
 
 constexpr int kWave = 64;
 
+// Sum over the 64 lanes with DPP adds (no LDS traffic). The total is valid in
+// lane 63 only. Fixed association order: bitwise reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  v = dpp_add<0xb1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);  // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);  // row_ror:8   -> every lane holds its row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
   return v;
 }
+constexpr int kSumLane = 63;
 
 // Sum over the block, in a fixed order (bitwise reproducible). The result is
 // valid in thread 0. `red` holds NT/64 floats. Contains two barriers.
@@ -35,7 +47,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   __syncthreads();
-  if (lane == 0) red[wid] = v;
+  if (lane == kSumLane) red[wid] = v;
   __syncthreads();
   float t = 0.f;
   if (threadIdx.x == 0) {

@@ -8,37 +8,72 @@
 // written one IEEE operation at a time in a fixed association order and this
 // file is compiled with -ffp-contract=off, so those outputs are reproducible
 // bit for bit by any IEEE float32 evaluation of the same expressions.
-// Backward arithmetic uses explicit fmaf where it helps.
+// Backward arithmetic uses explicit fmaf and fast reciprocals where it helps.
 //
 // Launch sequence of one training step:
-//   forward : disp_mean_kernel -> photo_tile_kernel<GRAD> -> smooth_kernel
+//   forward : disp_sum_kernel -> photo_tile_kernel<GRAD> -> smooth_kernel
 //             -> loss_finalize_kernel
 //   backward: grad_disp_kernel -> grad_pose_kernel
 // photo_tile_kernel<true> does the whole per-pixel backward at unit upstream
-// gradient while the tile is still on chip and leaves d loss / d (up-sampled
-// disparity) and per-tile pose partials in the workspace; the two backward
-// kernels only finish the adjoint of the up-sampling, the smoothness term and
-// the deterministic cross-tile sums, scaled by the upstream gradient.
+// gradient while the tile is still on chip, including the adjoint of the
+// disparity up-sampling restricted to the tile, and leaves per-tile partial
+// sums in the workspace; the backward kernels add the partials of neighbouring
+// tiles in a fixed order, add the smoothness term and scale by the upstream
+// gradient.  No atomics anywhere: results are bitwise reproducible.
+//
+// Tile geometry.  A block owns an "error-map region" Q of QH x 64 pixels, one
+// 1xSW strip per thread (NT = QH * 64/SW threads).  The colour / warped region R is
+// Q plus one pixel on every side (3x3 SSIM window).  With gradients, the pixels
+// a block is responsible for (its "core") are Q minus one pixel on every side,
+// because the adjoint of the window sums at a pixel needs the error terms of
+// its eight neighbours; tiles therefore step by (QH-2) x 62.  Forward-only
+// blocks have core = Q and step by QH x 64.
 #include "dw_common.h"
 
 namespace dw {
 
-constexpr int TH = 16;   // tile rows
-constexpr int TW = 64;   // tile columns
-constexpr int NT = 512;  // threads per tile block (2 waves per SIMD; LDS allows one block per CU)
+constexpr int QH_GRAD = 16;  // error-map rows per block, gradient kernel
+constexpr int QH_FWD = 16;   // same, forward-only kernel
+constexpr int QW = 64;       // error-map columns per block
+constexpr int SW = 2;        // pixels per thread strip (1 x SW); 2 or 4
+constexpr int WW = SW + 2;   // strip window columns
+constexpr int SPR = QW / SW; // strips per error-map row
+constexpr int BLOCKS_PER_CU = 1;  // what LDS and registers are budgeted for
+constexpr int RW = QW + 2;   // region columns
+constexpr int RP = 68;       // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
 constexpr int SM_NT = 256;
 
+template <bool GRAD>
+struct Geom {
+  static constexpr int QH = GRAD ? QH_GRAD : QH_FWD;
+  static constexpr int NT = QH * SPR;
+  static constexpr int MINW = NT / 64 * BLOCKS_PER_CU / 4;  // waves per SIMD to stay under
+  static constexpr int RH = QH + 2;
+  static constexpr int CO = GRAD ? 1 : 0;  // core offset inside Q
+  static constexpr int CH = QH - 2 * CO;   // core rows = tile step
+  static constexpr int CW = QW - 2 * CO;   // core columns = tile step
+};
+constexpr int G_CH = Geom<true>::CH, G_CW = Geom<true>::CW;
+
+// Largest number of low-resolution rows / columns of scale s that the core of
+// one gradient tile can touch through the bilinear up-sampling taps.
+__host__ __device__ constexpr int part_rows(int s) { return (G_CH - 1) / (1 << s) + 3; }
+__host__ __device__ constexpr int part_cols(int s) { return (G_CW - 1) / (1 << s) + 3; }
+__host__ __device__ constexpr int part_size(int s) { return part_rows(s) * part_cols(s); }
+constexpr int MAX_TMP = G_CH * part_cols(1);
+
 struct ScaleLayout {
   int Hs[DW_MAX_SCALES], Ws[DW_MAX_SCALES];
-  int nblk[DW_MAX_SCALES];         // blocks per image at scale s
-  int blk_off[DW_MAX_SCALES + 1];  // prefix sum of B * nblk[s]
-  long pix_off[DW_MAX_SCALES + 1]; // prefix sum of B * Hs * Ws
+  int nblk[DW_MAX_SCALES];          // blocks per image at scale s (map kernels)
+  int blk_off[DW_MAX_SCALES + 1];   // prefix sum of B * nblk[s]
+  long pix_off[DW_MAX_SCALES + 1];  // prefix sum of B * Hs * Ws
+  long part_off[DW_MAX_SCALES + 1]; // prefix sum of B * tiles * part_size(s), s >= 1
 };
 
 struct PhotoParams {
   int B, H, W, S;
-  int tilesX, tilesY;
+  int tilesX, tilesY;  // of the kernel being launched
   const float* disp[DW_MAX_SCALES];
   const float* color[3];
   const float* pyr[DW_MAX_SCALES];
@@ -48,10 +83,11 @@ struct PhotoParams {
   const float* tie;
   uint8_t* mask[DW_MAX_SCALES];
   // workspace sections
-  float* mean;       // [S][B]
-  float* tile_loss;  // [B][tiles][S]
+  float* sum_part;   // [blk_off[S]]            partial sums of disp[s]
+  float* tile_loss;  // [B][tiles][4]
   float* tile_dP;    // [B][tiles][24]
-  float* gdup;       // [S][B][H][W]
+  float* gd0;        // [B][H][W]               d loss / d disp[0], photometric part
+  float* part;       // [part_off[S]]           per-tile up-sampling adjoint partials, s >= 1
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
   float* sm_part;    // [blk_off[S]][3]
   ScaleLayout L;
@@ -70,15 +106,25 @@ __device__ __forceinline__ float upsampled_disp(const float* __restrict__ d, int
   return ty.l0 * top + ty.l1 * bot;
 }
 
+// Weight with which full-resolution index `dst` contributes to low-resolution
+// index `j` in the bilinear up-sampling (0 if j is not one of its two taps).
+__device__ __forceinline__ float upsample_weight(int dst, int j, int in_size, float scale) {
+  const Taps t = upsample_taps(dst, in_size, scale);
+  return (t.i0 == j ? t.l0 : 0.f) + (t.i1 == j ? t.l1 : 0.f);
+}
+
+// Load from a uniform base pointer plus a 32-bit per-lane byte offset.
+__device__ __forceinline__ float tap(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 struct Sample {
-  // forward
   float val[3];
   bool valid;
-  // what the backward needs
   float u, v, zp;
   float tx, ty;
   bool inx, iny;
-  int o_nw, o_ne, o_sw, o_se;
+  unsigned o_nw, o_ne, o_sw, o_se;  // BYTE offsets of the four taps inside a plane
 };
 
 // Project the camera-space point (X,Y,Z) with P (3x4, row-major) and sample
@@ -108,14 +154,17 @@ __device__ __forceinline__ void project_sample(const float* __restrict__ src, lo
   const int x0 = (int)ix0, y0 = (int)iy0;
   const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
   const float w_nw = ex * ey, w_ne = tx * ey, w_sw = ex * ty, w_se = tx * ty;
-  o.o_nw = y0 * W + x0;
-  o.o_ne = y0 * W + x1;
-  o.o_sw = y1 * W + x0;
-  o.o_se = y1 * W + x1;
+  o.o_nw = (unsigned)(y0 * W + x0) * 4u;
+  o.o_ne = (unsigned)(y0 * W + x1) * 4u;
+  o.o_sw = (unsigned)(y1 * W + x0) * 4u;
+  o.o_se = (unsigned)(y1 * W + x1) * 4u;
+  // uniform plane base + 32-bit per-lane offset: scalar-base addressing, no
+  // 64-bit address arithmetic per tap
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* p = src + c * plane;
-    o.val[c] = ((p[o.o_nw] * w_nw + p[o.o_ne] * w_ne) + p[o.o_sw] * w_sw) + p[o.o_se] * w_se;
+    o.val[c] = ((tap(p, o.o_nw) * w_nw + tap(p, o.o_ne) * w_ne) + tap(p, o.o_sw) * w_sw) +
+               tap(p, o.o_se) * w_se;
   }
   o.u = u;
   o.v = v;
@@ -124,25 +173,32 @@ __device__ __forceinline__ void project_sample(const float* __restrict__ src, lo
   o.ty = ty;
 }
 
-// 3x3 sums around `pos` of a region image with row pitch RW: per column
-// (top + mid) + bot, then (left + centre) + right.
-__device__ __forceinline__ float box3_sum(const float* a, int pos, int RW) {
-  const float c0 = (a[pos - RW - 1] + a[pos - 1]) + a[pos + RW - 1];
-  const float c1 = (a[pos - RW] + a[pos]) + a[pos + RW];
-  const float c2 = (a[pos - RW + 1] + a[pos + 1]) + a[pos + RW + 1];
-  return (c0 + c1) + c2;
+// The WW consecutive 32-bit words of one window row in LDS (start aligned to SW words).
+template <typename T>
+__device__ __forceinline__ void loadw(const T* p, T* o) {
+  static_assert(sizeof(T) == 4, "32-bit elements");
+  if (SW == 4) {
+    const int4 a = *reinterpret_cast<const int4*>(p);
+    const int2 b = *reinterpret_cast<const int2*>(p + 4);
+    const int v[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+#pragma unroll
+    for (int j = 0; j < WW; ++j) o[j] = __builtin_bit_cast(T, v[j]);
+  } else {
+    const int2 a = *reinterpret_cast<const int2*>(p);
+    const int2 b = *reinterpret_cast<const int2*>(p + 2);
+    const int v[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+    for (int j = 0; j < WW; ++j) o[j] = __builtin_bit_cast(T, v[j % 4]);
+  }
 }
-__device__ __forceinline__ float box3_sum_prod(const float* a, const float* b, int pos, int RW) {
-  const float c0 = (a[pos - RW - 1] * b[pos - RW - 1] + a[pos - 1] * b[pos - 1]) +
-                   a[pos + RW - 1] * b[pos + RW - 1];
-  const float c1 = (a[pos - RW] * b[pos - RW] + a[pos] * b[pos]) + a[pos + RW] * b[pos + RW];
-  const float c2 = (a[pos - RW + 1] * b[pos - RW + 1] + a[pos + 1] * b[pos + 1]) +
-                   a[pos + RW + 1] * b[pos + RW + 1];
-  return (c0 + c1) + c2;
+
+// A value that is the same in every lane, moved to a scalar register.
+__device__ __forceinline__ float uniform(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
 struct SsimTerms {
-  float A1, A2, B1, B2, raw;
+  float A1, A2, B1, B2, r, raw;
 };
 
 __device__ __forceinline__ float ssim_loss_px(float mux, float muy, float exx, float eyy,
@@ -156,44 +212,59 @@ __device__ __forceinline__ float ssim_loss_px(float mux, float muy, float exx, f
   t.B2 = (sx + sy) + kC2;
   const float n = t.A1 * t.A2;
   const float d = t.B1 * t.B2;
-  t.raw = (1.0f - n / d) * 0.5f;
+  t.r = n / d;
+  t.raw = (1.0f - t.r) * 0.5f;
   return fminf(fmaxf(t.raw, 0.f), 1.f);
+}
+
+// 3x3 window sums of one strip: column sums (top + mid) + bot for the six
+// columns, then (left + centre) + right per pixel.
+__device__ __forceinline__ void colsum3(const float a[3][WW], float cs[WW]) {
+#pragma unroll
+  for (int j = 0; j < WW; ++j) cs[j] = (a[0][j] + a[1][j]) + a[2][j];
+}
+__device__ __forceinline__ void colsum3_prod(const float a[3][WW], const float b[3][WW], float cs[WW]) {
+#pragma unroll
+  for (int j = 0; j < WW; ++j) cs[j] = (a[0][j] * b[0][j] + a[1][j] * b[1][j]) + a[2][j] * b[2][j];
+}
+__device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
+  return ((cs[p] + cs[p + 1]) + cs[p + 2]) * kNinth;
 }
 
 // ------------------------------------------------------------ the tile kernel
 template <bool GRAD>
-struct TileShape {
-  static constexpr int HALO = GRAD ? 2 : 1;
-  static constexpr int RW = TW + 2 * HALO, RH = TH + 2 * HALO, R = RW * RH;  // warped / colour region
-  static constexpr int QW = RW - 2, QH = RH - 2, Q = QW * QH;                // error-map region
-};
-
-template <bool GRAD>
-__global__ __launch_bounds__(NT) void photo_tile_kernel(const PhotoParams p) {
-  using G = TileShape<GRAD>;
-  constexpr int HALO = G::HALO, RW = G::RW, RH = G::RH, R = G::R, QW = G::QW, QH = G::QH,
-                Q = G::Q;
-  __shared__ float s_tgt[3][R];
-  __shared__ float s_xw[2][3][R];
-  __shared__ float s_ystat[6][Q];  // per channel: mean, E[y^2]
-  __shared__ float s_idm[Q];       // min of the two identity errors
-  __shared__ unsigned char s_idi[Q];
-  __shared__ unsigned char s_valid[R];
-  __shared__ float s_G[GRAD ? 9 : 1][GRAD ? Q : 1];
-  __shared__ signed char s_sel[GRAD ? Q : 1];
+__global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_kernel(const PhotoParams p) {
+  using Gm = Geom<GRAD>;
+  constexpr int QH = Gm::QH, NT = Gm::NT, RH = Gm::RH, CO = Gm::CO, CH = Gm::CH, CW = Gm::CW;
+  constexpr int RN = RH * RP;  // floats per region plane
+  constexpr int GN = QH * RP;  // floats per adjoint-coefficient plane
+  constexpr int UNION = (6 * RN > 9 * GN) ? 6 * RN : 9 * GN;
+  __shared__ __attribute__((aligned(16))) float s_tgt[3 * RN];
+  // warped sources [2][3][RN] during stages A-B; SSIM adjoint coefficients
+  // [9][GN] during stage C (written after every thread is done with A-B data)
+  __shared__ __attribute__((aligned(16))) float s_un[GRAD ? UNION : 6 * RN];
+  __shared__ float s_depth[DW_MAX_SCALES * RN];  // depth of every region pixel at every scale
+  __shared__ unsigned char s_valid[RN];
+  __shared__ __attribute__((aligned(16))) int s_sel[GRAD ? GN : 4];  // winning frame (-1: none)
+  __shared__ float s_gd[GRAD ? QH * QW : 1];
+  __shared__ float s_tmp[GRAD ? MAX_TMP : 1];
   __shared__ float s_P[2][12];
   __shared__ float s_invK[9];
   __shared__ float s_red[NT / kWave];
+  __shared__ float s_dPw[GRAD ? (NT / kWave) * 24 : 1];  // per-wave pose partials of one scale
 
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
   const int b = blockIdx.y;
   const int tY = tile / p.tilesX, tX = tile - tY * p.tilesX;
-  const int y00 = tY * TH - HALO, x00 = tX * TW - HALO;  // image coords of region (0,0)
+  const int cy0 = tY * CH, cx0 = tX * CW;        // image coords of the core origin
+  const int qy0 = cy0 - CO, qx0 = cx0 - CO;      // ... of Q(0,0)
+  const int ry0 = qy0 - 1, rx0 = qx0 - 1;        // ... of R(0,0)
   const int H = p.H, W = p.W;
   const long plane = (long)H * W;
+  const int qr = tid / SPR, ql = tid % SPR;      // this thread's strip: Q row, Q cols SW*ql..
+  const int win = qr * RP + SW * ql;              // region index of the strip's window corner
 
-  // ---- per-sample camera constants: P[f] = (K @ T[f])[:3], inv_K[:3,:3]
   if (tid < 24) {
     const int f = tid / 12, ij = tid - f * 12, i = ij >> 2, j = ij & 3;
     const float* Kb = p.K + (long)b * 16;
@@ -209,245 +280,332 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const PhotoParams p) {
   // ---- colour regions (reflect-mapped): target and the two un-warped sources
   const float* tgt_b = p.color[0] + (long)b * 3 * plane;
   const float* src_b[2] = {p.color[1] + (long)b * 3 * plane, p.color[2] + (long)b * 3 * plane};
-  for (int i = tid; i < R; i += NT) {
+  for (int i = tid; i < RH * RW; i += NT) {
     const int ry = i / RW, rx = i - ry * RW;
-    const int y = reflect_index(y00 + ry, H), x = reflect_index(x00 + rx, W);
+    const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
     const long o = (long)y * W + x;
+    const int li = ry * RP + rx;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      s_tgt[c][i] = tgt_b[c * plane + o];
-      s_xw[0][c][i] = src_b[0][c * plane + o];
-      s_xw[1][c][i] = src_b[1][c * plane + o];
+      s_tgt[c * RN + li] = tgt_b[c * plane + o];
+      s_un[(0 * 3 + c) * RN + li] = src_b[0][c * plane + o];
+      s_un[(1 * 3 + c) * RN + li] = src_b[1][c * plane + o];
+    }
+    // depth from the up-sampled disparity of every scale, once per tile: the
+    // per-scale stages then have no dependent global load in front of the taps
+    for (int s = 0; s < p.S; ++s) {
+      const int hs = H >> s, ws = W >> s;
+      const float du = upsampled_disp(p.disp[s] + (long)b * hs * ws, hs, ws, s, y, x,
+                                      (float)hs / (float)H, (float)ws / (float)W);
+      s_depth[s * RN + li] = 1.0f / (kMinDisp + kDispRange * du);
     }
   }
   __syncthreads();
 
-  // Photometric error of frame f at error-map position (qy, qx) from the
-  // region images; optionally returns the SSIM terms per channel.
-  auto photo_error = [&](int f, int pos, int q, SsimTerms* terms, float* mux_out) -> float {
-    float ss[3], l1[3];
+  // camera constants into scalar registers (uniform over the block)
+  float P0[12], P1[12], iK[9];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    P0[k] = uniform(s_P[0][k]);
+    P1[k] = uniform(s_P[1][k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) iK[k] = uniform(s_invK[k]);
+
+  // image coordinates and status of the pixels of this thread's strip
+  const int sy_img = qy0 + qr;
+  const int sx_img = qx0 + SW * ql;
+  const bool row_in = (sy_img >= 0 && sy_img < H);
+  const bool row_core = row_in && (qr >= CO) && (qr < QH - CO);
+
+  // ---- target window statistics (kept in registers for every scale)
+  float muy[3][SW], eyy[3][SW];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float y[3][WW], cs[WW], cyy[WW];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) loadw(&s_tgt[c * RN + win + r * RP], y[r]);
+    colsum3(y, cs);
+    colsum3_prod(y, y, cyy);
+#pragma unroll
+    for (int q = 0; q < SW; ++q) {
+      muy[c][q] = rowsum3(cs, q);
+      eyy[c][q] = rowsum3(cyy, q);
+    }
+  }
+
+  // Photometric errors of both frames for the strip, from the region images in
+  // LDS. E[f][q]; with gradients also the SSIM adjoint coefficients Gc[f][q][9].
+  auto strip_errors = [&](float E[2][SW], float Gc[2][SW][9], bool want_g) __attribute__((always_inline)) {
+    float ss[2][SW], l1[2][SW];  // channel sums, accumulated in channel order
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float* xa = s_xw[f][c];
-      const float* ya = s_tgt[c];
-      const float mux = box3_sum(xa, pos, RW) * kNinth;
-      const float exx = box3_sum_prod(xa, xa, pos, RW) * kNinth;
-      const float exy = box3_sum_prod(xa, ya, pos, RW) * kNinth;
-      const float muy = s_ystat[2 * c][q], eyy = s_ystat[2 * c + 1][q];
-      SsimTerms t;
-      ss[c] = ssim_loss_px(mux, muy, exx, eyy, exy, t);
-      l1[c] = fabsf(xa[pos] - ya[pos]);
-      if (terms) {
-        terms[c] = t;
-        mux_out[c] = mux;
+      float y[3][WW];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) loadw(&s_tgt[c * RN + win + r * RP], y[r]);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float x[3][WW], cs[WW], cxx[WW], cxy[WW];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) loadw(&s_un[(f * 3 + c) * RN + win + r * RP], x[r]);
+        colsum3(x, cs);
+        colsum3_prod(x, x, cxx);
+        colsum3_prod(x, y, cxy);
+#pragma unroll
+        for (int q = 0; q < SW; ++q) {
+          const float mux = rowsum3(cs, q), exx = rowsum3(cxx, q), exy = rowsum3(cxy, q);
+          SsimTerms t;
+          const float sv = ssim_loss_px(mux, muy[c][q], exx, eyy[c][q], exy, t);
+          const float lv = fabsf(x[1][q + 1] - y[1][q + 1]);
+          ss[f][q] = (c == 0) ? sv : ss[f][q] + sv;
+          l1[f][q] = (c == 0) ? lv : l1[f][q] + lv;
+          if (GRAD && want_g) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (t.raw >= 0.f && t.raw <= 1.f) {
+              // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2, 1/d
+              const float up = (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2);
+              g0 = up * (2.0f * muy[c][q] * (t.A2 - t.A1) - t.r * 2.0f * mux * (t.B2 - t.B1));
+              g1 = up * (-t.r * t.B1);
+              g2 = up * (2.0f * t.A1);
+            }
+            Gc[f][q][3 * c + 0] = g0;
+            Gc[f][q][3 * c + 1] = g1;
+            Gc[f][q][3 * c + 2] = g2;
+          }
+        }
+        // keep the scheduler from interleaving the six (channel, frame) bodies:
+        // that would hold every window of the strip in registers at once
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    const float ms = ((ss[0] + ss[1]) + ss[2]) * kThird;
-    const float ml = ((l1[0] + l1[1]) + l1[2]) * kThird;
-    return kWSsim * ms + kWL1 * ml;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int q = 0; q < SW; ++q) {
+        E[f][q] = kWSsim * (ss[f][q] * kThird) + kWL1 * (l1[f][q] * kThird);
+      }
   };
 
-  // ---- target statistics and identity errors over the error-map region
-  for (int q = tid; q < Q; q += NT) {
-    const int qy = q / QW, qx = q - qy * QW;
-    const int pos = (qy + 1) * RW + (qx + 1);
+  // ---- identity errors (scale independent): min of the two and its index
+  float idm[SW];
+  int idi[SW];
+  {
+    float E[2][SW];
+    strip_errors(E, nullptr, false);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      s_ystat[2 * c][q] = box3_sum(s_tgt[c], pos, RW) * kNinth;
-      s_ystat[2 * c + 1][q] = box3_sum_prod(s_tgt[c], s_tgt[c], pos, RW) * kNinth;
-    }
-  }
-  __syncthreads();
-  for (int q = tid; q < Q; q += NT) {
-    const int qy = q / QW, qx = q - qy * QW;
-    const int pos = (qy + 1) * RW + (qx + 1);
-    const int y = y00 + 1 + qy, x = x00 + 1 + qx;
-    float m = 0.f;
-    unsigned char mi = 0;
-    if (y >= 0 && y < H && x >= 0 && x < W) {
-      float e0 = photo_error(0, pos, q, nullptr, nullptr);
-      float e1 = photo_error(1, pos, q, nullptr, nullptr);
-      if (p.tie) {
-        const long o = (long)y * W + x;
+    for (int q = 0; q < SW; ++q) {
+      const int x = sx_img + q;
+      float e0 = E[0][q], e1 = E[1][q];
+      if (p.tie && row_in && x >= 0 && x < W) {
+        const long o = (long)sy_img * W + x;
         e0 = e0 + p.tie[((long)b * DW_NUM_SRC + 0) * plane + o];
         e1 = e1 + p.tie[((long)b * DW_NUM_SRC + 1) * plane + o];
       }
-      m = e0;
-      if (e1 < m) {
-        m = e1;
-        mi = 1;
+      idm[q] = e0;
+      idi[q] = 0;
+      if (e1 < e0) {
+        idm[q] = e1;
+        idi[q] = 1;
       }
     }
-    s_idm[q] = m;
-    s_idi[q] = mi;
   }
-  __syncthreads();
+  __syncthreads();  // un-warped sources no longer needed: stage A may overwrite them
 
   const long tslot = (long)b * p.tilesX * p.tilesY + tile;
-  float dP[2][12];
-#pragma unroll
-  for (int f = 0; f < 2; ++f)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) dP[f][k] = 0.f;
+  float dP_total = 0.f;  // threads 0..23: one entry of the 2x3x4 projection gradient
 
   for (int s = 0; s < p.S; ++s) {
     const int hs = H >> s, ws = W >> s;
     const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
-    const float* disp_b = p.disp[s] + (long)b * hs * ws;
     float loss_acc = 0.f;
 
-    // ---- stage A: warp both sources over the colour region
-    for (int i = tid; i < R; i += NT) {
+    // ---- stage A: warp both sources over the region
+#pragma unroll 1
+    for (int i0 = tid; i0 < RH * RW; i0 += NT) {
+      int i = i0;
+      asm volatile("" : "+v"(i));  // keep per-pixel geometry from being hoisted out of the scale loop
       const int ry = i / RW, rx = i - ry * RW;
-      const int y = reflect_index(y00 + ry, H), x = reflect_index(x00 + rx, W);
-      const float du = upsampled_disp(disp_b, hs, ws, s, y, x, sy, sx);
-      const float depth = 1.0f / (kMinDisp + kDispRange * du);
+      const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
+      const int li = ry * RP + rx;
+      const float depth = s_depth[s * RN + li];
       const float fx = (float)x, fy = (float)y;
-      const float X = depth * ((s_invK[0] * fx + s_invK[1] * fy) + s_invK[2]);
-      const float Y = depth * ((s_invK[3] * fx + s_invK[4] * fy) + s_invK[5]);
-      const float Z = depth * ((s_invK[6] * fx + s_invK[7] * fy) + s_invK[8]);
+      const float X = depth * ((iK[0] * fx + iK[1] * fy) + iK[2]);
+      const float Y = depth * ((iK[3] * fx + iK[4] * fy) + iK[5]);
+      const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
       unsigned char vb = 0;
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         Sample sm;
-        project_sample(src_b[f], plane, H, W, s_P[f], X, Y, Z, sm);
-        s_xw[f][0][i] = sm.val[0];
-        s_xw[f][1][i] = sm.val[1];
-        s_xw[f][2][i] = sm.val[2];
+        project_sample(src_b[f], plane, H, W, f ? P1 : P0, X, Y, Z, sm);
+        s_un[(f * 3 + 0) * RN + li] = sm.val[0];
+        s_un[(f * 3 + 1) * RN + li] = sm.val[1];
+        s_un[(f * 3 + 2) * RN + li] = sm.val[2];
         vb |= (sm.valid ? 1 : 0) << (2 + f);
+        __builtin_amdgcn_sched_barrier(0);  // one frame's taps in flight at a time
       }
-      s_valid[i] = vb;
+      s_valid[li] = vb;
     }
     __syncthreads();
 
-    // ---- stage B: errors, minimum, mask; SSIM adjoint terms of the winner
-    for (int q = tid; q < Q; q += NT) {
-      const int qy = q / QW, qx = q - qy * QW;
-      const int pos = (qy + 1) * RW + (qx + 1);
-      const int y = y00 + 1 + qy, x = x00 + 1 + qx;
-      const bool inside = (y >= 0 && y < H && x >= 0 && x < W);
-      signed char sel = -1;
-      float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (inside) {
-        SsimTerms t0[3], t1[3];
-        float mx0[3], mx1[3];
-        const float e0 = photo_error(0, pos, q, GRAD ? t0 : nullptr, mx0);
-        const float e1 = photo_error(1, pos, q, GRAD ? t1 : nullptr, mx1);
-        float m = s_idm[q];
-        int idx = s_idi[q];
-        if (e0 < m) {
-          m = e0;
-          idx = 2;
-        }
-        if (e1 < m) {
-          m = e1;
-          idx = 3;
-        }
-        const bool core = (qy >= HALO - 1) && (qy < HALO - 1 + TH) && (qx >= HALO - 1) &&
-                          (qx < HALO - 1 + TW);
-        if (core) {
-          loss_acc += m;
-          if (p.mask[s]) p.mask[s][(long)b * plane + (long)y * W + x] = (uint8_t)(idx | s_valid[pos]);
-        }
-        if (GRAD && idx >= 2) {
-          sel = (signed char)(idx - 2);
+    // ---- stage B: errors of the strip, minimum, mask; adjoint coefficients
+    float E[2][SW];
+    float Gc[GRAD ? 2 : 1][SW][9];
+    strip_errors(E, GRAD ? Gc : nullptr, true);
+    int sel[SW];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const SsimTerms t = (idx == 2) ? t0[c] : t1[c];
-            const float mux = (idx == 2) ? mx0[c] : mx1[c];
-            const float muy = s_ystat[2 * c][q];
-            if (t.raw >= 0.f && t.raw <= 1.f) {
-              const float d = t.B1 * t.B2;
-              const float r = (t.A1 * t.A2) / d;
-              const float inv_d = 1.0f / d;
-              // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2
-              const float up = -0.5f * kWSsim * kThird * inv_d;
-              g[3 * c + 0] = up * (2.0f * muy * (t.A2 - t.A1) - r * 2.0f * mux * (t.B2 - t.B1));
-              g[3 * c + 1] = up * (-r * t.B1);
-              g[3 * c + 2] = up * (2.0f * t.A1);
-            }
-          }
-        }
+    for (int q = 0; q < SW; ++q) {
+      const int x = sx_img + q;
+      const bool inside = row_in && x >= 0 && x < W;
+      float m = idm[q];
+      int idx = idi[q];
+      if (E[0][q] < m) {
+        m = E[0][q];
+        idx = 2;
       }
-      if (GRAD) {
-        s_sel[q] = sel;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s_G[k][q] = g[k];
+      if (E[1][q] < m) {
+        m = E[1][q];
+        idx = 3;
+      }
+      sel[q] = (inside && idx >= 2) ? idx - 2 : -1;
+      const int qc = SW * ql + q;
+      if (inside && row_core && qc >= CO && qc < QW - CO) {
+        loss_acc += m;
+        if (p.mask[s])
+          p.mask[s][(long)b * plane + (long)sy_img * W + x] =
+              (uint8_t)(idx | s_valid[win + RP + 1 + q]);
       }
     }
-    __syncthreads();
 
-    // ---- stage C: adjoint of window sums, L1, warp, projection, depth
     if (GRAD) {
-      for (int i = tid; i < TH * TW; i += NT) {
-        const int cy = i / TW, cx = i - cy * TW;
-        const int y = y00 + HALO + cy, x = x00 + HALO + cx;
-        if (y >= H || x >= W) continue;
-        const int q0 = (cy + HALO - 1) * QW + (cx + HALO - 1);  // this pixel in error-map coords
-        const int pos = (cy + HALO) * RW + (cx + HALO);         // and in region coords
-        float acc[2][9];
+      __syncthreads();  // every thread has read the warped images: reuse their LDS
+      // coefficient planes are indexed [k][Q row][Q col + 1]
+#pragma unroll
+      for (int q = 0; q < SW; ++q) {
+        const int gi = qr * RP + SW * ql + q + 1;
+        s_sel[gi] = sel[q];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float g = (sel[q] == 1) ? Gc[GRAD ? 1 : 0][q][k] : Gc[0][q][k];
+          s_un[k * GN + gi] = (sel[q] < 0) ? 0.f : g;
+        }
+      }
+      if (ql == 0) s_sel[qr * RP] = -1;  // column left of Q: no pixel
+      if (ql == SPR - 1) {
+        s_sel[qr * RP + QW + 1] = -1;
+        s_sel[qr * RP + QW + 2] = -1;
+        s_sel[qr * RP + QW + 3] = -1;
+      }
+      __syncthreads();
+
+      // ---- stage C: adjoint of the window sums, L1, warp, projection, depth
+      float gd[SW];
+#pragma unroll
+      for (int q = 0; q < SW; ++q) gd[q] = 0.f;
+      float dP[2][12];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dP[f][k] = 0.f;
+      if (row_core) {
+        // a window row / column that was reflected onto this pixel's row /
+        // column counts twice
+        float wy[3], wx[SW][3];
+        wy[0] = (sy_img == 1) ? 2.f : 1.f;
+        wy[1] = 1.f;
+        wy[2] = (sy_img == H - 2) ? 2.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < SW; ++q) {
+          const int x = sx_img + q;
+          wx[q][0] = (x == 1) ? 2.f : 1.f;
+          wx[q][1] = 1.f;
+          wx[q][2] = (x == W - 2) ? 2.f : 1.f;
+        }
+        // winning frame of the 3x6 neighbourhood (Q rows qr-1..qr+1, cols 4ql-1..4ql+4)
+        int nsel[3][WW];
+        const int gwin = (qr - 1) * RP + SW * ql;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) loadw(&s_sel[gwin + r * RP], nsel[r]);
+        bool any[2][SW];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int k = 0; k < 9; ++k) acc[f][k] = 0.f;
-        bool any = false;
+          for (int q = 0; q < SW; ++q) {
+            bool a = false;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-          // a window row that was reflected onto this pixel's row counts twice
-          const float wy = 1.f + ((dy == -1 && y == 1) ? 1.f : 0.f) +
-                           ((dy == 1 && y == H - 2) ? 1.f : 0.f);
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int dx = -1; dx <= 1; ++dx) {
-            const float wx = 1.f + ((dx == -1 && x == 1) ? 1.f : 0.f) +
-                             ((dx == 1 && x == W - 2) ? 1.f : 0.f);
-            const int q = q0 + dy * QW + dx;
-            const int sel = s_sel[q];
-            if (sel < 0) continue;
-            any = true;
-            const float w = wy * wx;
+              for (int j = 0; j < 3; ++j) a = a || (nsel[r][q + j] == f);
+            any[f][q] = a;
+          }
+        // per-pixel geometry shared by both frames
+        float depth[SW], r0[SW], r1[SW], r2[SW];
+        bool live[SW];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-              const float gk = s_G[k][q] * w;
-              if (sel == 0) acc[0][k] += gk; else acc[1][k] += gk;
-            }
+        for (int q = 0; q < SW; ++q) {
+          const int x = sx_img + q, qc = SW * ql + q;
+          live[q] = (qc >= CO && qc < QW - CO && x < W) && (any[0][q] || any[1][q]);
+          depth[q] = 0.f;
+          r0[q] = r1[q] = r2[q] = 0.f;
+          if (live[q]) {
+            depth[q] = s_depth[s * RN + win + RP + 1 + q];
+            const float fx = (float)x, fy = (float)sy_img;
+            r0[q] = (iK[0] * fx + iK[1] * fy) + iK[2];
+            r1[q] = (iK[3] * fx + iK[4] * fy) + iK[5];
+            r2[q] = (iK[6] * fx + iK[7] * fy) + iK[8];
           }
         }
-        float gd = 0.f;
-        if (any) {
-          const float du = upsampled_disp(disp_b, hs, ws, s, y, x, sy, sx);
-          const float depth = 1.0f / (kMinDisp + kDispRange * du);
-          const float fx = (float)x, fy = (float)y;
-          const float r0 = (s_invK[0] * fx + s_invK[1] * fy) + s_invK[2];
-          const float r1 = (s_invK[3] * fx + s_invK[4] * fy) + s_invK[5];
-          const float r2 = (s_invK[6] * fx + s_invK[7] * fy) + s_invK[8];
-          const float X = depth * r0, Y = depth * r1, Z = depth * r2;
-          const int my_sel = s_sel[q0];
-          float gdepth = 0.f;
+        float gdepth[SW];
 #pragma unroll
-          for (int f = 0; f < 2; ++f) {
+        for (int q = 0; q < SW; ++q) gdepth[q] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          // window-sum adjoint of frame f: column sums over the three rows, then
+          // the three columns of each pixel
+          float acc[SW][9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            float g[3][WW], cs[WW];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) loadw(&s_un[k * GN + gwin + r * RP], g[r]);
+#pragma unroll
+            for (int j = 0; j < WW; ++j) {
+              const float a0 = (nsel[0][j] == f) ? g[0][j] : 0.f;
+              const float a1 = (nsel[1][j] == f) ? g[1][j] : 0.f;
+              const float a2 = (nsel[2][j] == f) ? g[2][j] : 0.f;
+              cs[j] = fmaf(wy[0], a0, fmaf(wy[2], a2, a1));
+            }
+#pragma unroll
+            for (int q = 0; q < SW; ++q)
+              acc[q][k] = fmaf(wx[q][0], cs[q], fmaf(wx[q][2], cs[q + 2], cs[q + 1]));
+          }
+#pragma unroll
+          for (int q = 0; q < SW; ++q) {
+            if (!(live[q] && any[f][q])) continue;
+            const float X = depth[q] * r0[q], Y = depth[q] * r1[q], Z = depth[q] * r2[q];
             Sample sm;
-            project_sample(src_b[f], plane, H, W, s_P[f], X, Y, Z, sm);
+            project_sample(src_b[f], plane, H, W, f ? P1 : P0, X, Y, Z, sm);
             float gix = 0.f, giy = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              const float xq = s_xw[f][c][pos], yq = s_tgt[c][pos];
-              float gx = kNinth * (acc[f][3 * c] + 2.0f * xq * acc[f][3 * c + 1] +
-                                   yq * acc[f][3 * c + 2]);
-              if (my_sel == f) {
+              const float xq = sm.val[c], yq = s_tgt[c * RN + win + RP + 1 + q];
+              float gx = kNinth * (acc[q][3 * c] + 2.0f * xq * acc[q][3 * c + 1] +
+                                   yq * acc[q][3 * c + 2]);
+              if (sel[q] == f) {
                 const float df = xq - yq;
                 gx += kWL1 * kThird * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
               }
               const float* pc = src_b[f] + c * plane;
-              const float nw = pc[sm.o_nw], ne = pc[sm.o_ne], sw = pc[sm.o_sw], se = pc[sm.o_se];
+              const float nw = tap(pc, sm.o_nw), ne = tap(pc, sm.o_ne), sw = tap(pc, sm.o_sw),
+                          se = tap(pc, sm.o_se);
               gix = fmaf(gx, (ne - nw) * (1.f - sm.ty) + (se - sw) * sm.ty, gix);
               giy = fmaf(gx, (sw - nw) * (1.f - sm.tx) + (se - ne) * sm.tx, giy);
             }
             const float gu = sm.inx ? gix : 0.f;
             const float gv = sm.iny ? giy : 0.f;
-            const float iz = 1.0f / sm.zp;
+            const float iz = __builtin_amdgcn_rcpf(sm.zp);
             const float gc0 = gu * iz, gc1 = gv * iz;
             const float gc2 = -(gu * sm.u + gv * sm.v) * iz;
-            const float* P = s_P[f];
+            const float* P = f ? P1 : P0;
             dP[f][0] = fmaf(gc0, X, dP[f][0]);
             dP[f][1] = fmaf(gc0, Y, dP[f][1]);
             dP[f][2] = fmaf(gc0, Z, dP[f][2]);
@@ -463,45 +621,78 @@ __global__ __launch_bounds__(NT) void photo_tile_kernel(const PhotoParams p) {
             const float gX = gc0 * P[0] + gc1 * P[4] + gc2 * P[8];
             const float gY = gc0 * P[1] + gc1 * P[5] + gc2 * P[9];
             const float gZ = gc0 * P[2] + gc1 * P[6] + gc2 * P[10];
-            gdepth += gX * r0 + gY * r1 + gZ * r2;
+            gdepth[q] += gX * r0[q] + gY * r1[q] + gZ * r2[q];
           }
-          gd = gdepth * (-kDispRange * depth * depth);
         }
-        p.gdup[((long)s * p.B + b) * plane + (long)y * W + x] = gd;
+#pragma unroll
+        for (int q = 0; q < SW; ++q) gd[q] = gdepth[q] * (-kDispRange * depth[q] * depth[q]);
+      }
+      // pose partials of this scale: one value per wave and entry
+      {
+        const int lane = tid & (kWave - 1), wid = tid / kWave;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int k = 0; k < 12; ++k) {
+            const float v = wave_sum(dP[f][k]);
+            if (lane == kSumLane) s_dPw[wid * 24 + f * 12 + k] = v;
+          }
+      }
+      if (s == 0) {
+        if (row_core) {
+#pragma unroll
+          for (int q = 0; q < SW; ++q) {
+            const int x = sx_img + q, qc = SW * ql + q;
+            if (qc >= CO && qc < QW - CO && x < W)
+              p.gd0[(long)b * plane + (long)sy_img * W + x] = gd[q];
+          }
+        }
+      } else {
+        // ---- stage D: adjoint of the bilinear up-sampling, restricted to this
+        // tile's core; rows first, then columns (both from LDS)
+        #pragma unroll
+        for (int q = 0; q < SW; ++q) s_gd[qr * QW + SW * ql + q] = gd[q];
+        __syncthreads();
+        const int Y1 = min(cy0 + CH, H) - 1, X1 = min(cx0 + CW, W) - 1;
+        const int k2 = 1 << s;
+        const int ilo = upsample_taps(cy0, hs, sy).i0, ihi = upsample_taps(Y1, hs, sy).i1;
+        const int jlo = upsample_taps(cx0, ws, sx).i0, jhi = upsample_taps(X1, ws, sx).i1;
+        const int nrow = ihi - ilo + 1, ncol = jhi - jlo + 1, nY = Y1 - cy0 + 1;
+        const int pc_max = part_cols(s);
+        for (int e = tid; e < nY * ncol; e += NT) {
+          const int yr = e / ncol, jj = e - yr * ncol, j = jlo + jj;
+          const int Xa = max(cx0, (j - 1) * k2 + k2 / 2), Xb = min(X1, (j + 1) * k2 + k2 / 2 - 1);
+          float a = 0.f;
+          for (int X = Xa; X <= Xb; ++X)
+            a = fmaf(upsample_weight(X, j, ws, sx), s_gd[(yr + CO) * QW + (X - cx0 + CO)], a);
+          s_tmp[yr * pc_max + jj] = a;
+        }
+        __syncthreads();
+        float* part = p.part + p.L.part_off[s] + tslot * part_size(s);
+        for (int e = tid; e < nrow * ncol; e += NT) {
+          const int ii = e / ncol, jj = e - ii * ncol, i = ilo + ii;
+          const int Ya = max(cy0, (i - 1) * k2 + k2 / 2), Yb = min(Y1, (i + 1) * k2 + k2 / 2 - 1);
+          float a = 0.f;
+          for (int Y = Ya; Y <= Yb; ++Y)
+            a = fmaf(upsample_weight(Y, i, hs, sy), s_tmp[(Y - cy0) * pc_max + jj], a);
+          part[ii * pc_max + jj] = a;
+        }
       }
     }
-    // per-tile partial sum (fixed order: reproducible run to run); its
-    // barriers also separate this scale's LDS reads from the next stage A
+    // per-tile partial sum (fixed order: reproducible run to run); its barriers
+    // also separate this scale's LDS traffic from the next stage A
     const float t = block_sum<NT>(loss_acc, s_red);
     if (tid == 0) p.tile_loss[tslot * DW_MAX_SCALES + s] = t;
-  }
-
-  if (GRAD) {
+    if (GRAD && tid < 24) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const float t = block_sum<NT>(dP[f][k], s_red);
-        if (tid == 0) p.tile_dP[tslot * 24 + f * 12 + k] = t;
-      }
+      for (int w = 0; w < NT / kWave; ++w) dP_total += s_dPw[w * 24 + tid];
+    }
   }
+  if (GRAD && tid < 24) p.tile_dP[tslot * 24 + tid] = dP_total;
 }
 
-// ------------------------------------------------- per-image disparity means
-__global__ __launch_bounds__(1024) void disp_mean_kernel(const PhotoParams p) {
-  __shared__ float red[1024 / kWave];
-  const int s = blockIdx.y, b = blockIdx.x;
-  if (s >= p.S) return;
-  const long n = (long)p.L.Hs[s] * p.L.Ws[s];
-  const float* d = p.disp[s] + (long)b * n;
-  float acc = 0.f;
-  for (long i = threadIdx.x; i < n; i += 1024) acc += d[i];
-  const float t = block_sum<1024>(acc, red);
-  if (threadIdx.x == 0) p.mean[s * p.B + b] = t / (float)n;
-}
-
-// Decode a block of the per-scale map kernels: scale, sample, first pixel.
-__device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, int B, int blk, int& s,
+// Decode a block of the per-scale map kernels: scale, sample, chunk.
+__device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, int blk, int& s,
                                                  int& b, int& chunk) {
   s = 0;
   while (s + 1 < S && blk >= L.blk_off[s + 1]) ++s;
@@ -510,20 +701,49 @@ __device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, in
   chunk = r - b * L.nblk[s];
 }
 
+// ------------------------------------------------- partial sums of disp[s]
+__global__ __launch_bounds__(SM_NT) void disp_sum_kernel(const PhotoParams p) {
+  __shared__ float red[SM_NT / kWave];
+  int s, b, chunk;
+  decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
+  const long n = (long)p.L.Hs[s] * p.L.Ws[s];
+  const float* d = p.disp[s] + (long)b * n;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
+    const long i = (long)chunk * SM_PX + k;
+    if (i < n) acc += d[i];
+  }
+  const float t = block_sum<SM_NT>(acc, red);
+  if (threadIdx.x == 0) p.sum_part[blockIdx.x] = t;
+}
+
+// Mean of disp[s][b] from the per-block partial sums, fixed order; every
+// thread of the block gets the value. `red` holds SM_NT/64 + 1 floats.
+__device__ __forceinline__ float image_mean(const float* sum_part, const ScaleLayout& L, int s,
+                                            int b, float* red) {
+  const long base = (long)L.blk_off[s] + (long)b * L.nblk[s];
+  float a = 0.f;
+  for (int k = threadIdx.x; k < L.nblk[s]; k += SM_NT) a += sum_part[base + k];
+  const float t = block_sum<SM_NT>(a, red);
+  if (threadIdx.x == 0) red[SM_NT / kWave] = t / (float)((long)L.Hs[s] * L.Ws[s]);
+  __syncthreads();
+  return red[SM_NT / kWave];
+}
+
 // ------------------------------------------------- edge-aware smoothness
 // loss_s = mean_x(|d^(x) - d^(x+1)| * exp(-mean_c|I(x) - I(x+1)|)) + same in y,
 // d^ = disp / (mean + 1e-7).  Writes G = d loss_s / d d^ per pixel and per-block
 // partials (sum_x, sum_y, sum G*disp).
 template <bool GRAD>
 __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
-  __shared__ float red[SM_NT / kWave];
+  __shared__ float red[SM_NT / kWave + 1];
   int s, b, chunk;
-  decode_map_block(p.L, p.S, p.B, blockIdx.x, s, b, chunk);
+  decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
   const int hs = p.L.Hs[s], ws = p.L.Ws[s];
   const long n = (long)hs * ws;
   const float* d = p.disp[s] + (long)b * n;
   const float* I = p.pyr[s] + (long)b * 3 * n;
-  const float inv = 1.0f / (p.mean[s * p.B + b] + kMeanEps);
+  const float inv = 1.0f / (image_mean(p.sum_part, p.L, s, b, red) + kMeanEps);
   const float icx = 1.0f / ((float)p.B * hs * (ws - 1));
   const float icy = 1.0f / ((float)p.B * (hs - 1) * ws);
   float lx = 0.f, ly = 0.f, gd = 0.f;
@@ -574,52 +794,38 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
 }
 
 // ------------------------------------------------- scalar loss
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const PhotoParams p, float* loss_out) {
-  __shared__ double red[256];
-  const int tid = threadIdx.x;
+// One block; wave w (of 16) reduces one of the 3*S sums, in double, in a fixed order.
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p, float* loss_out) {
+  __shared__ double s_sum[3 * DW_MAX_SCALES];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const int ntile = p.B * p.tilesX * p.tilesY;
-  double total = 0.0;
-  for (int s = 0; s < p.S; ++s) {
+  if (wid < 3 * p.S) {
+    const int s = wid / 3, kind = wid - 3 * s;
     double a = 0.0;
-    for (int t = tid; t < ntile; t += 256) a += (double)p.tile_loss[(long)t * DW_MAX_SCALES + s];
-    red[tid] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
+    if (kind == 0) {
+      for (int t = lane; t < ntile; t += kWave) a += (double)p.tile_loss[(long)t * DW_MAX_SCALES + s];
+    } else {
+      for (int k = p.L.blk_off[s] + lane; k < p.L.blk_off[s + 1]; k += kWave)
+        a += (double)p.sm_part[(long)k * 3 + (kind - 1)];
     }
-    const double photo = red[0] / ((double)p.B * p.H * p.W);
-    __syncthreads();
-    double ax = 0.0, ay = 0.0;
-    for (int k = p.L.blk_off[s] + tid; k < p.L.blk_off[s + 1]; k += 256) {
-      ax += (double)p.sm_part[(long)k * 3 + 0];
-      ay += (double)p.sm_part[(long)k * 3 + 1];
-    }
-    red[tid] = ax;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    const double sumx = red[0];
-    __syncthreads();
-    red[tid] = ay;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    const double sumy = red[0];
-    __syncthreads();
-    const int hs = p.L.Hs[s], ws = p.L.Ws[s];
-    const double sm = sumx / ((double)p.B * hs * (ws - 1)) + sumy / ((double)p.B * (hs - 1) * ws);
-    if (tid == 0) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+    if (lane == 0) s_sum[wid] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+    for (int s = 0; s < p.S; ++s) {
+      const int hs = p.L.Hs[s], ws = p.L.Ws[s];
+      const double photo = s_sum[3 * s] / ((double)p.B * p.H * p.W);
+      const double sm = s_sum[3 * s + 1] / ((double)p.B * hs * (ws - 1)) +
+                        s_sum[3 * s + 2] / ((double)p.B * (hs - 1) * ws);
       loss_out[1 + s] = (float)photo;
       loss_out[1 + p.S + s] = (float)sm;
+      total += photo + (double)kWSmooth * sm / (double)(1 << s);
     }
-    total += photo + (double)kWSmooth * sm / (double)(1 << s);
+    loss_out[0] = (float)(total / p.S);
   }
-  if (tid == 0) loss_out[0] = (float)(total / p.S);
 }
 
 // ------------------------------------------------- backward: d loss / d disp[s]
@@ -629,9 +835,10 @@ struct BwdParams {
   const float* disp[DW_MAX_SCALES];
   const float* K;
   const float* grad_loss;
-  const float* mean;
+  const float* sum_part;
   const float* tile_dP;
-  const float* gdup;
+  const float* gd0;
+  const float* part;
   const float* sm_G;
   const float* sm_part;
   float* grad_disp[DW_MAX_SCALES];
@@ -640,16 +847,16 @@ struct BwdParams {
 };
 
 __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
+  __shared__ float red[SM_NT / kWave + 1];
   __shared__ float s_gd;
-  __shared__ float red[SM_NT / kWave];
   int s, b, chunk;
-  decode_map_block(p.L, p.S, p.B, blockIdx.x, s, b, chunk);
+  decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
   const int hs = p.L.Hs[s], ws = p.L.Ws[s];
   const long n = (long)hs * ws;
   const int H = p.H, W = p.W;
   const long plane = (long)H * W;
-  // sum_i G_i * disp_i over the whole image, from the per-block partials
-  {
+  const float mean = image_mean(p.sum_part, p.L, s, b, red);
+  {  // sum_i G_i * disp_i over the whole image, from the per-block partials
     float a = 0.f;
     const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
     for (int k = threadIdx.x; k < p.L.nblk[s]; k += SM_NT) a += p.sm_part[(base + k) * 3 + 2];
@@ -658,38 +865,38 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
     __syncthreads();
   }
   const float go = p.grad_loss[0];
-  const float inv = 1.0f / (p.mean[s * p.B + b] + kMeanEps);
+  const float inv = 1.0f / (mean + kMeanEps);
   const float coef = go * (kWSmooth / (float)(1 << s)) / (float)p.S;
   const float g0 = go / ((float)p.S * (float)p.B * (float)plane);
   const float mean_term = s_gd * inv * inv / (float)n;
-  const float* gdup = p.gdup + ((long)s * p.B + b) * plane;
   const float* G = p.sm_G + p.L.pix_off[s] + (long)b * n;
   float* out = p.grad_disp[s] + (long)b * n;
   const int k2 = 1 << s;
   const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
+  const int ntile = p.tilesX * p.tilesY;
+  const int pc_max = part_cols(s);
   for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
     const long i = (long)chunk * SM_PX + k;
     if (i >= n) break;
     const int y = (int)(i / ws), x = (int)(i - (long)y * ws);
     float ph = 0.f;
     if (s == 0) {
-      ph = gdup[i];
+      ph = p.gd0[(long)b * plane + i];
     } else {
-      // adjoint of the bilinear up-sampling in gather form: every full-res
-      // pixel one of whose taps is (y, x)
-      const int Y0 = max(0, (y - 1) * k2 + k2 / 2), Y1 = min(H - 1, (y + 1) * k2 + k2 / 2 - 1);
-      const int X0 = max(0, (x - 1) * k2 + k2 / 2), X1 = min(W - 1, (x + 1) * k2 + k2 / 2 - 1);
-      for (int Y = Y0; Y <= Y1; ++Y) {
-        const Taps ty = upsample_taps(Y, hs, sy);
-        const float wy = (ty.i0 == y ? ty.l0 : 0.f) + (ty.i1 == y ? ty.l1 : 0.f);
-        if (wy == 0.f) continue;
-        float row = 0.f;
-        for (int X = X0; X <= X1; ++X) {
-          const Taps tx = upsample_taps(X, ws, sx);
-          const float wx = (tx.i0 == x ? tx.l0 : 0.f) + (tx.i1 == x ? tx.l1 : 0.f);
-          row = fmaf(wx, gdup[(long)Y * W + X], row);
+      // every tile whose core holds a full-resolution pixel with a tap at (y, x)
+      const int Ya = max(0, (y - 1) * k2 + k2 / 2), Yb = min(H - 1, (y + 1) * k2 + k2 / 2 - 1);
+      const int Xa = max(0, (x - 1) * k2 + k2 / 2), Xb = min(W - 1, (x + 1) * k2 + k2 / 2 - 1);
+      for (int tY = Ya / G_CH; tY <= Yb / G_CH; ++tY) {
+        const int cy0 = tY * G_CH, Y1 = min(cy0 + G_CH, H) - 1;
+        const int ilo = upsample_taps(cy0, hs, sy).i0, ihi = upsample_taps(Y1, hs, sy).i1;
+        if (y < ilo || y > ihi) continue;
+        for (int tX = Xa / G_CW; tX <= Xb / G_CW; ++tX) {
+          const int cx0 = tX * G_CW, X1 = min(cx0 + G_CW, W) - 1;
+          const int jlo = upsample_taps(cx0, ws, sx).i0, jhi = upsample_taps(X1, ws, sx).i1;
+          if (x < jlo || x > jhi) continue;
+          const long slot = (long)b * ntile + (long)tY * p.tilesX + tX;
+          ph += p.part[p.L.part_off[s] + slot * part_size(s) + (y - ilo) * pc_max + (x - jlo)];
         }
-        ph = fmaf(wy, row, ph);
       }
     }
     out[i] = coef * (G[i] * inv - mean_term) + g0 * ph;
@@ -697,14 +904,22 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
 }
 
 // ------------------------------------------------- backward: d loss / d T
-__global__ __launch_bounds__(64) void grad_pose_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256) void grad_pose_kernel(const BwdParams p) {
+  __shared__ double s_part[10][24];
   __shared__ double s_dP[24];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int ntile = p.tilesX * p.tilesY;
+  if (tid < 240) {
+    const int g = tid / 24, k = tid - g * 24;
+    double a = 0.0;
+    const float* src = p.tile_dP + (long)b * ntile * 24 + k;
+    for (int t = g; t < ntile; t += 10) a += (double)src[(long)t * 24];
+    s_part[g][k] = a;
+  }
+  __syncthreads();
   if (tid < 24) {
     double a = 0.0;
-    const float* src = p.tile_dP + (long)b * ntile * 24 + tid;
-    for (int t = 0; t < ntile; ++t) a += (double)src[(long)t * 24];
+    for (int g = 0; g < 10; ++g) a += s_part[g][tid];
     s_dP[tid] = a;
   }
   __syncthreads();
@@ -720,14 +935,24 @@ __global__ __launch_bounds__(64) void grad_pose_kernel(const BwdParams p) {
 
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t mean, tile_loss, tile_dP, gdup, sm_G, sm_part, total;
+  size_t sum_part, tile_loss, tile_dP, gd0, part, sm_G, sm_part, total;
 };
 
-static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, int& tilesX, int& tilesY) {
-  tilesX = (d.W + TW - 1) / TW;
-  tilesY = (d.H + TH - 1) / TH;
+struct TileCounts {
+  int gX, gY;  // gradient kernel
+  int fX, fY;  // forward-only kernel
+};
+
+static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCounts& tc) {
+  tc.gX = (d.W + Geom<true>::CW - 1) / Geom<true>::CW;
+  tc.gY = (d.H + Geom<true>::CH - 1) / Geom<true>::CH;
+  tc.fX = (d.W + Geom<false>::CW - 1) / Geom<false>::CW;
+  tc.fY = (d.H + Geom<false>::CH - 1) / Geom<false>::CH;
+  const size_t tiles_g = (size_t)tc.gX * tc.gY;
+  const size_t tiles_max = tiles_g > (size_t)tc.fX * tc.fY ? tiles_g : (size_t)tc.fX * tc.fY;
   L.blk_off[0] = 0;
   L.pix_off[0] = 0;
+  L.part_off[0] = 0;
   for (int s = 0; s < DW_MAX_SCALES; ++s) {
     if (s < d.S) {
       L.Hs[s] = d.H >> s;
@@ -739,21 +964,25 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, int& tile
     }
     L.blk_off[s + 1] = L.blk_off[s] + d.B * L.nblk[s];
     L.pix_off[s + 1] = L.pix_off[s] + (long)d.B * L.Hs[s] * L.Ws[s];
+    L.part_off[s + 1] =
+        L.part_off[s] + ((s >= 1 && s < d.S) ? (long)d.B * tiles_g * part_size(s) : 0);
   }
   const size_t A = 256;
   size_t o = 0;
-  w.mean = o;
-  o = align_up(o + sizeof(float) * DW_MAX_SCALES * d.B, A);
+  w.sum_part = o;
+  o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S], A);
   w.tile_loss = o;
-  o = align_up(o + sizeof(float) * (size_t)d.B * tilesX * tilesY * DW_MAX_SCALES, A);
+  o = align_up(o + sizeof(float) * (size_t)d.B * tiles_max * DW_MAX_SCALES, A);
   w.tile_dP = o;
-  o = align_up(o + sizeof(float) * (size_t)d.B * tilesX * tilesY * 24, A);
+  o = align_up(o + sizeof(float) * (size_t)d.B * tiles_g * 24, A);
   w.sm_part = o;
   o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S] * 3, A);
   w.sm_G = o;
   o = align_up(o + sizeof(float) * (size_t)L.pix_off[d.S], A);
-  w.gdup = o;
-  o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
+  w.part = o;
+  o = align_up(o + sizeof(float) * (size_t)L.part_off[d.S], A);
+  w.gd0 = o;
+  o = align_up(o + sizeof(float) * (size_t)d.B * d.H * d.W, A);
   w.total = o;
 }
 
@@ -776,8 +1005,8 @@ extern "C" size_t dw_photometric_workspace_bytes(const dw_desc* desc) {
   if (check_desc(desc) != DW_OK) return 0;
   ScaleLayout L;
   WsLayout w;
-  int tx, ty;
-  make_layout(*desc, L, w, tx, ty);
+  TileCounts tc;
+  make_layout(*desc, L, w, tc);
   return w.total;
 }
 
@@ -793,12 +1022,15 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
     return DW_ERR_NULL;
   PhotoParams p{};
   WsLayout w;
-  make_layout(*desc, p.L, w, p.tilesX, p.tilesY);
+  TileCounts tc;
+  make_layout(*desc, p.L, w, tc);
   if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return DW_ERR_WORKSPACE;
   p.B = desc->B;
   p.H = desc->H;
   p.W = desc->W;
   p.S = desc->S;
+  p.tilesX = with_grad ? tc.gX : tc.fX;
+  p.tilesY = with_grad ? tc.gY : tc.fY;
   for (int s = 0; s < desc->S; ++s) {
     if (!disp[s] || !color_pyr[s]) return DW_ERR_NULL;
     p.disp[s] = disp[s];
@@ -814,10 +1046,11 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.T = T;
   p.tie = tie_noise;
   char* ws = (char*)workspace;
-  p.mean = (float*)(ws + w.mean);
+  p.sum_part = (float*)(ws + w.sum_part);
   p.tile_loss = (float*)(ws + w.tile_loss);
   p.tile_dP = (float*)(ws + w.tile_dP);
-  p.gdup = (float*)(ws + w.gdup);
+  p.gd0 = (float*)(ws + w.gd0);
+  p.part = (float*)(ws + w.part);
   p.sm_G = (float*)(ws + w.sm_G);
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
@@ -825,20 +1058,20 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   const dim3 tgrid(p.tilesX * p.tilesY, p.B);
   if (desc->flags & DW_FLAG_TILE_KERNEL_ONLY) {
     if (with_grad)
-      photo_tile_kernel<true><<<tgrid, NT, 0, st>>>(p);
+      photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
     else
-      photo_tile_kernel<false><<<tgrid, NT, 0, st>>>(p);
+      photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
     return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
   }
-  disp_mean_kernel<<<dim3(p.B, p.S), 1024, 0, st>>>(p);
+  disp_sum_kernel<<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   if (with_grad) {
-    photo_tile_kernel<true><<<tgrid, NT, 0, st>>>(p);
+    photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
     smooth_kernel<true><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   } else {
-    photo_tile_kernel<false><<<tgrid, NT, 0, st>>>(p);
+    photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
     smooth_kernel<false><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   }
-  loss_finalize_kernel<<<1, 256, 0, st>>>(p, loss_out);
+  loss_finalize_kernel<<<1, 1024, 0, st>>>(p, loss_out);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
 
@@ -851,12 +1084,15 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   if (!disp || !K || !grad_loss || !workspace || !grad_disp) return DW_ERR_NULL;
   BwdParams p{};
   WsLayout w;
-  make_layout(*desc, p.L, w, p.tilesX, p.tilesY);
+  TileCounts tc;
+  make_layout(*desc, p.L, w, tc);
   if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return DW_ERR_WORKSPACE;
   p.B = desc->B;
   p.H = desc->H;
   p.W = desc->W;
   p.S = desc->S;
+  p.tilesX = tc.gX;
+  p.tilesY = tc.gY;
   for (int s = 0; s < desc->S; ++s) {
     if (!disp[s] || !grad_disp[s]) return DW_ERR_NULL;
     p.disp[s] = disp[s];
@@ -865,14 +1101,15 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   p.K = K;
   p.grad_loss = grad_loss;
   const char* ws = (const char*)workspace;
-  p.mean = (const float*)(ws + w.mean);
+  p.sum_part = (const float*)(ws + w.sum_part);
   p.tile_dP = (const float*)(ws + w.tile_dP);
-  p.gdup = (const float*)(ws + w.gdup);
+  p.gd0 = (const float*)(ws + w.gd0);
+  p.part = (const float*)(ws + w.part);
   p.sm_G = (const float*)(ws + w.sm_G);
   p.sm_part = (const float*)(ws + w.sm_part);
   p.grad_T = grad_T;
   hipStream_t st = (hipStream_t)stream;
   grad_disp_kernel<<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
-  if (grad_T) grad_pose_kernel<<<p.B, 64, 0, st>>>(p);
+  if (grad_T) grad_pose_kernel<<<p.B, 256, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }

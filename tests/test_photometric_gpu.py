@@ -99,7 +99,8 @@ def test_forward_only_matches_training_forward():
     disp = [d.clone().requires_grad_(True) for d in seq.disp]
     t1, m1 = ops.photometric_forward(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, seq.T)
     assert torch.equal(m0, m1)
-    assert torch.equal(t0, t1.detach())
+    # the two kernels tile the image differently, so their partial sums group differently
+    assert torch.allclose(t0, t1.detach(), rtol=1e-6, atol=0)
 
 
 def test_hip_matches_committed_golden_vectors():
