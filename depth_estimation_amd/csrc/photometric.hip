@@ -122,13 +122,13 @@ struct Sample {
   float val[3];
   bool valid;
   float u, v, zp;
-  float tx, ty;
   bool inx, iny;
-  unsigned o_nw, o_ne, o_sw, o_se;  // BYTE offsets of the four taps inside a plane
+  float dx[3], dy[3];  // d val[c] / d (sample x, y) in pixels, before the border mask
 };
 
 // Project the camera-space point (X,Y,Z) with P (3x4, row-major) and sample
 // the three colour planes of `src` bilinearly (border padding, corners aligned).
+template <bool WITH_GRAD>
 __device__ __forceinline__ void project_sample(const float* __restrict__ src, long plane, int H,
                                                int W, const float* P, float X, float Y, float Z,
                                                Sample& o) {
@@ -154,23 +154,23 @@ __device__ __forceinline__ void project_sample(const float* __restrict__ src, lo
   const int x0 = (int)ix0, y0 = (int)iy0;
   const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
   const float w_nw = ex * ey, w_ne = tx * ey, w_sw = ex * ty, w_se = tx * ty;
-  o.o_nw = (unsigned)(y0 * W + x0) * 4u;
-  o.o_ne = (unsigned)(y0 * W + x1) * 4u;
-  o.o_sw = (unsigned)(y1 * W + x0) * 4u;
-  o.o_se = (unsigned)(y1 * W + x1) * 4u;
+  const unsigned o_nw = (unsigned)(y0 * W + x0) * 4u, o_ne = (unsigned)(y0 * W + x1) * 4u;
+  const unsigned o_sw = (unsigned)(y1 * W + x0) * 4u, o_se = (unsigned)(y1 * W + x1) * 4u;
   // uniform plane base + 32-bit per-lane offset: scalar-base addressing, no
   // 64-bit address arithmetic per tap
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* p = src + c * plane;
-    o.val[c] = ((tap(p, o.o_nw) * w_nw + tap(p, o.o_ne) * w_ne) + tap(p, o.o_sw) * w_sw) +
-               tap(p, o.o_se) * w_se;
+    const float nw = tap(p, o_nw), ne = tap(p, o_ne), sw = tap(p, o_sw), se = tap(p, o_se);
+    o.val[c] = ((nw * w_nw + ne * w_ne) + sw * w_sw) + se * w_se;
+    if (WITH_GRAD) {
+      o.dx[c] = fmaf(se - sw, ty, (ne - nw) * ey);
+      o.dy[c] = fmaf(se - ne, tx, (sw - nw) * ex);
+    }
   }
   o.u = u;
   o.v = v;
   o.zp = zp;
-  o.tx = tx;
-  o.ty = ty;
 }
 
 // The WW consecutive 32-bit words of one window row in LDS (start aligned to SW words).
@@ -231,6 +231,26 @@ __device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
   return ((cs[p] + cs[p + 1]) + cs[p + 2]) * kNinth;
 }
 
+// Diagnostic build only (-DDW_STAMPS): per-wave cycle sums of the kernel's
+// segments, taken with s_memtime. The sums of one tile overwrite the start of
+// the gd0 workspace section, so that build's gradients are not usable.
+#ifdef DW_STAMPS
+#define DW_STAMP_DECL                               \
+  unsigned long long t_last, t_acc[10];             \
+  for (int k_ = 0; k_ < 10; ++k_) t_acc[k_] = 0;    \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#define DW_STAMP(k)                                                                  \
+  {                                                                                  \
+    unsigned long long t_now;                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
+    t_acc[k] += t_now - t_last;                                                      \
+    t_last = t_now;                                                                  \
+  }
+#else
+#define DW_STAMP_DECL
+#define DW_STAMP(k)
+#endif
+
 // ------------------------------------------------------------ the tile kernel
 template <bool GRAD>
 __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_kernel(const PhotoParams p) {
@@ -244,15 +264,22 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   // [9][GN] during stage C (written after every thread is done with A-B data)
   __shared__ __attribute__((aligned(16))) float s_un[GRAD ? UNION : 6 * RN];
   __shared__ float s_depth[DW_MAX_SCALES * RN];  // depth of every region pixel at every scale
-  __shared__ unsigned char s_valid[RN];
-  __shared__ __attribute__((aligned(16))) int s_sel[GRAD ? GN : 4];  // winning frame (-1: none)
-  __shared__ float s_gd[GRAD ? QH * QW : 1];
+  // d loss / d disp_up of the tile (stage D, scales >= 1) reuses the depth plane of scale 0
+  float* const s_gd = s_depth;
+  static_assert(!GRAD || QH * QW <= RN, "s_gd must fit one depth plane");
+  // per error-map pixel and frame: warped colour (3), its x / y derivatives (3 + 3); stage A -> C
+  __shared__ __attribute__((aligned(16))) float s_st[GRAD ? 2 * 9 * QH * QW : 4];
+  // per region pixel: bits 2,3 validity of source 0,1, bits 0,1 / 6,7 sample strictly inside the
+  // image in x,y for source 0 / 1 (stage A); bits 4,5 winning frame + 1
+  // (stage B; 0 = no re-projection won, or not a pixel of the error map)
+  __shared__ __attribute__((aligned(8))) unsigned char s_valid[RN];
   __shared__ float s_tmp[GRAD ? MAX_TMP : 1];
   __shared__ float s_P[2][12];
   __shared__ float s_invK[9];
   __shared__ float s_red[NT / kWave];
   __shared__ float s_dPw[GRAD ? (NT / kWave) * 24 : 1];  // per-wave pose partials of one scale
 
+  DW_STAMP_DECL
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
   const int b = blockIdx.y;
@@ -301,6 +328,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     }
   }
   __syncthreads();
+  DW_STAMP(8)  // region + depth loads
 
   // camera constants into scalar registers (uniform over the block)
   float P0[12], P1[12], iK[9];
@@ -410,6 +438,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     }
   }
   __syncthreads();  // un-warped sources no longer needed: stage A may overwrite them
+  DW_STAMP(9)  // target statistics + identity errors
 
   const long tslot = (long)b * p.tilesX * p.tilesY + tile;
   float dP_total = 0.f;  // threads 0..23: one entry of the 2x3x4 projection gradient
@@ -419,6 +448,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
     float loss_acc = 0.f;
 
+    DW_STAMP(0)
     // ---- stage A: warp both sources over the region
 #pragma unroll 1
     for (int i0 = tid; i0 < RH * RW; i0 += NT) {
@@ -436,16 +466,29 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         Sample sm;
-        project_sample(src_b[f], plane, H, W, f ? P1 : P0, X, Y, Z, sm);
+        project_sample<GRAD>(src_b[f], plane, H, W, f ? P1 : P0, X, Y, Z, sm);
         s_un[(f * 3 + 0) * RN + li] = sm.val[0];
         s_un[(f * 3 + 1) * RN + li] = sm.val[1];
         s_un[(f * 3 + 2) * RN + li] = sm.val[2];
         vb |= (sm.valid ? 1 : 0) << (2 + f);
-        __builtin_amdgcn_sched_barrier(0);  // one frame's taps in flight at a time
+        if (GRAD) {
+          vb |= ((sm.inx ? 1 : 0) | (sm.iny ? 2 : 0)) << (6 * f);
+          if (ry >= 1 && ry <= QH && rx >= 1 && rx <= QW) {
+            float* st = &s_st[f * 9 * QH * QW + (ry - 1) * QW + (rx - 1)];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              st[(c + 0) * QH * QW] = sm.val[c];
+              st[(c + 3) * QH * QW] = sm.dx[c];
+              st[(c + 6) * QH * QW] = sm.dy[c];
+            }
+          }
+        }
       }
       s_valid[li] = vb;
     }
+    DW_STAMP(1)  // stage A
     __syncthreads();
+    DW_STAMP(2)  // barrier after A
 
     // ---- stage B: errors of the strip, minimum, mask; adjoint coefficients
     float E[2][SW];
@@ -468,35 +511,30 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
       }
       sel[q] = (inside && idx >= 2) ? idx - 2 : -1;
       const int qc = SW * ql + q;
+      const unsigned char vb = s_valid[win + RP + 1 + q];
       if (inside && row_core && qc >= CO && qc < QW - CO) {
         loss_acc += m;
-        if (p.mask[s])
-          p.mask[s][(long)b * plane + (long)sy_img * W + x] =
-              (uint8_t)(idx | s_valid[win + RP + 1 + q]);
+        if (p.mask[s]) p.mask[s][(long)b * plane + (long)sy_img * W + x] = (uint8_t)(idx | (vb & 0x0c));
       }
+      if (GRAD) s_valid[win + RP + 1 + q] = (unsigned char)(vb | ((sel[q] + 1) << 4));
     }
 
+    DW_STAMP(3)  // stage B
     if (GRAD) {
       __syncthreads();  // every thread has read the warped images: reuse their LDS
       // coefficient planes are indexed [k][Q row][Q col + 1]
 #pragma unroll
       for (int q = 0; q < SW; ++q) {
         const int gi = qr * RP + SW * ql + q + 1;
-        s_sel[gi] = sel[q];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const float g = (sel[q] == 1) ? Gc[GRAD ? 1 : 0][q][k] : Gc[0][q][k];
           s_un[k * GN + gi] = (sel[q] < 0) ? 0.f : g;
         }
       }
-      if (ql == 0) s_sel[qr * RP] = -1;  // column left of Q: no pixel
-      if (ql == SPR - 1) {
-        s_sel[qr * RP + QW + 1] = -1;
-        s_sel[qr * RP + QW + 2] = -1;
-        s_sel[qr * RP + QW + 3] = -1;
-      }
       __syncthreads();
 
+      DW_STAMP(4)  // coefficient planes + barriers
       // ---- stage C: adjoint of the window sums, L1, warp, projection, depth
       float gd[SW];
 #pragma unroll
@@ -524,7 +562,22 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         int nsel[3][WW];
         const int gwin = (qr - 1) * RP + SW * ql;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) loadw(&s_sel[gwin + r * RP], nsel[r]);
+        for (int r = 0; r < 3; ++r) {
+          // region rows qr-1+1 .. qr+1+1, region columns SW*ql .. SW*ql+WW-1
+          const unsigned char* vrow = &s_valid[(qr + r) * RP + SW * ql];
+          unsigned w[2];
+          if (SW == 4) {
+            const uint2 w2 = *reinterpret_cast<const uint2*>(vrow);
+            w[0] = w2.x;
+            w[1] = w2.y;
+          } else {
+            w[0] = *reinterpret_cast<const unsigned short*>(vrow) |
+                   ((unsigned)*reinterpret_cast<const unsigned short*>(vrow + 2) << 16);
+            w[1] = 0;
+          }
+#pragma unroll
+          for (int j = 0; j < WW; ++j) nsel[r][j] = (int)((w[j >> 2] >> (8 * (j & 3) + 4)) & 3) - 1;
+        }
         bool any[2][SW];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -582,30 +635,32 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           for (int q = 0; q < SW; ++q) {
             if (!(live[q] && any[f][q])) continue;
             const float X = depth[q] * r0[q], Y = depth[q] * r1[q], Z = depth[q] * r2[q];
-            Sample sm;
-            project_sample(src_b[f], plane, H, W, f ? P1 : P0, X, Y, Z, sm);
+            const float* P = f ? P1 : P0;
+            const float* st = &s_st[f * 9 * QH * QW + qr * QW + SW * ql + q];
             float gix = 0.f, giy = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              const float xq = sm.val[c], yq = s_tgt[c * RN + win + RP + 1 + q];
+              const float xq = st[c * QH * QW], yq = s_tgt[c * RN + win + RP + 1 + q];
               float gx = kNinth * (acc[q][3 * c] + 2.0f * xq * acc[q][3 * c + 1] +
                                    yq * acc[q][3 * c + 2]);
               if (sel[q] == f) {
                 const float df = xq - yq;
                 gx += kWL1 * kThird * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
               }
-              const float* pc = src_b[f] + c * plane;
-              const float nw = tap(pc, sm.o_nw), ne = tap(pc, sm.o_ne), sw = tap(pc, sm.o_sw),
-                          se = tap(pc, sm.o_se);
-              gix = fmaf(gx, (ne - nw) * (1.f - sm.ty) + (se - sw) * sm.ty, gix);
-              giy = fmaf(gx, (sw - nw) * (1.f - sm.tx) + (se - ne) * sm.tx, giy);
+              gix = fmaf(gx, st[(c + 3) * QH * QW], gix);
+              giy = fmaf(gx, st[(c + 6) * QH * QW], giy);
             }
-            const float gu = sm.inx ? gix : 0.f;
-            const float gv = sm.iny ? giy : 0.f;
-            const float iz = __builtin_amdgcn_rcpf(sm.zp);
+            // projection of the pixel again (registers only: no memory access)
+            const float c0 = fmaf(P[0], X, fmaf(P[1], Y, fmaf(P[2], Z, P[3])));
+            const float c1 = fmaf(P[4], X, fmaf(P[5], Y, fmaf(P[6], Z, P[7])));
+            const float c2 = fmaf(P[8], X, fmaf(P[9], Y, fmaf(P[10], Z, P[11])));
+            const float iz = __builtin_amdgcn_rcpf(c2 + kProjEps);
+            const float pu = c0 * iz, pv = c1 * iz;
+            const unsigned vbits = (unsigned)s_valid[win + RP + 1 + q] >> (6 * f);
+            const float gu = (vbits & 1) ? gix : 0.f;
+            const float gv = (vbits & 2) ? giy : 0.f;
             const float gc0 = gu * iz, gc1 = gv * iz;
-            const float gc2 = -(gu * sm.u + gv * sm.v) * iz;
-            const float* P = f ? P1 : P0;
+            const float gc2 = -(gu * pu + gv * pv) * iz;
             dP[f][0] = fmaf(gc0, X, dP[f][0]);
             dP[f][1] = fmaf(gc0, Y, dP[f][1]);
             dP[f][2] = fmaf(gc0, Z, dP[f][2]);
@@ -627,6 +682,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
 #pragma unroll
         for (int q = 0; q < SW; ++q) gd[q] = gdepth[q] * (-kDispRange * depth[q] * depth[q]);
       }
+      DW_STAMP(5)  // stage C
       // pose partials of this scale: one value per wave and entry
       {
         const int lane = tid & (kWave - 1), wid = tid / kWave;
@@ -681,14 +737,20 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     }
     // per-tile partial sum (fixed order: reproducible run to run); its barriers
     // also separate this scale's LDS traffic from the next stage A
+    DW_STAMP(6)  // pose partials + stage D
     const float t = block_sum<NT>(loss_acc, s_red);
     if (tid == 0) p.tile_loss[tslot * DW_MAX_SCALES + s] = t;
+    DW_STAMP(7)  // loss partial sum
     if (GRAD && tid < 24) {
 #pragma unroll
       for (int w = 0; w < NT / kWave; ++w) dP_total += s_dPw[w * 24 + tid];
     }
   }
   if (GRAD && tid < 24) p.tile_dP[tslot * 24 + tid] = dP_total;
+#ifdef DW_STAMPS
+  if (GRAD && (tid & 63) == 0 && tile == p.tilesX * (p.tilesY / 2) + p.tilesX / 2 && b == p.B / 2)
+    for (int k = 0; k < 10; ++k) p.gd0[(tid / 64) * 10 + k] = (float)t_acc[k];
+#endif
 }
 
 // Decode a block of the per-scale map kernels: scale, sample, chunk.

@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools/build_variant.sh NAME [extra hipcc flags / -D...]  -> variants/NAME.so
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p variants
+N=$1; shift
+hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -DDW_BUILD "$@" \
+  -Iinclude -Idepth_estimation_amd/csrc depth_estimation_amd/csrc/photometric.hip depth_estimation_amd/csrc/compute_loss.hip \
+  depth_estimation_amd/csrc/abi.hip $(ls depth_estimation_amd/csrc/modules.hip 2>/dev/null) -o variants/$N.so
