@@ -34,13 +34,13 @@ namespace dw {
 
 constexpr int QH_GRAD = 16;  // error-map rows per block, gradient kernel
 constexpr int QH_FWD = 16;   // same, forward-only kernel
-constexpr int QW = 64;       // error-map columns per block
+constexpr int QW = 32;       // error-map columns per block
 constexpr int SW = 2;        // pixels per thread strip (1 x SW); 2 or 4
 constexpr int WW = SW + 2;   // strip window columns
 constexpr int SPR = QW / SW; // strips per error-map row
-constexpr int BLOCKS_PER_CU = 1;  // what LDS and registers are budgeted for
+constexpr int BLOCKS_PER_CU = 2;  // what LDS and registers are budgeted for
 constexpr int RW = QW + 2;   // region columns
-constexpr int RP = 68;       // region row pitch in LDS (16-byte aligned rows)
+constexpr int RP = QW + 4;  // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
 constexpr int SM_NT = 256;
 
@@ -108,9 +108,11 @@ __device__ __forceinline__ float upsampled_disp(const float* __restrict__ d, int
 
 // Weight with which full-resolution index `dst` contributes to low-resolution
 // index `j` in the bilinear up-sampling (0 if j is not one of its two taps).
+// Equivalent tent form: max(0, 1 - |clamp(src, 0, in-1) - j|).
 __device__ __forceinline__ float upsample_weight(int dst, int j, int in_size, float scale) {
-  const Taps t = upsample_taps(dst, in_size, scale);
-  return (t.i0 == j ? t.l0 : 0.f) + (t.i1 == j ? t.l1 : 0.f);
+  float src = fmaf((float)dst + 0.5f, scale, -0.5f);
+  src = fminf(fmaxf(src, 0.f), (float)(in_size - 1));
+  return fmaxf(0.f, 1.0f - fabsf(src - (float)j));
 }
 
 // Load from a uniform base pointer plus a 32-bit per-lane byte offset.
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           const int yr = e / ncol, jj = e - yr * ncol, j = jlo + jj;
           const int Xa = max(cx0, (j - 1) * k2 + k2 / 2), Xb = min(X1, (j + 1) * k2 + k2 / 2 - 1);
           float a = 0.f;
+#pragma unroll 4
           for (int X = Xa; X <= Xb; ++X)
             a = fmaf(upsample_weight(X, j, ws, sx), s_gd[(yr + CO) * QW + (X - cx0 + CO)], a);
           s_tmp[yr * pc_max + jj] = a;
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           const int ii = e / ncol, jj = e - ii * ncol, i = ilo + ii;
           const int Ya = max(cy0, (i - 1) * k2 + k2 / 2), Yb = min(Y1, (i + 1) * k2 + k2 / 2 - 1);
           float a = 0.f;
+#pragma unroll 4
           for (int Y = Ya; Y <= Yb; ++Y)
             a = fmaf(upsample_weight(Y, i, hs, sy), s_tmp[(Y - cy0) * pc_max + jj], a);
           part[ii * pc_max + jj] = a;
