@@ -138,6 +138,57 @@ DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
                         const float* target, const float* pred, float* out,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Unfused building blocks (absent from the reference; the module interfaces
+ * of the public view-synthesis formulation).  Same arithmetic as the fused
+ * stack, one stage per call, for piecewise adoption and for testing.
+ * ------------------------------------------------------------------------- */
+
+/* scaled = min_disp + range * disp; depth = 1 / scaled   (n elements) */
+DW_API int dw_disp_to_depth_fwd(int64_t n, const float* disp, float min_disp, float range,
+                                float* scaled, float* depth, void* stream);
+/* g_disp = g_scaled * range - g_depth * range * depth^2; either upstream may be NULL */
+DW_API int dw_disp_to_depth_bwd(int64_t n, const float* depth, const float* g_scaled,
+                                const float* g_depth, float range, float* g_disp, void* stream);
+
+/* depth (B,1,H,W), inv_K (B,4,4) -> points (B,4,H*W) homogeneous camera points */
+DW_API int dw_backproject_fwd(int32_t B, int32_t H, int32_t W, const float* depth,
+                              const float* inv_K, float* points, void* stream);
+DW_API int dw_backproject_bwd(int32_t B, int32_t H, int32_t W, const float* inv_K,
+                              const float* g_points, float* g_depth, void* stream);
+
+/* points (B,4,H*W), K, T (B,4,4) -> grid (B,H,W,2), (x,y) last, in [-1,1] */
+DW_API int dw_project3d_fwd(int32_t B, int32_t H, int32_t W, const float* points, const float* K,
+                            const float* T, float eps, float* grid, void* stream);
+DW_API size_t dw_project3d_workspace_bytes(int32_t B, int32_t H, int32_t W);
+/* g_points (B,4,H*W) out; g_T (B,4,4) out or NULL (then no workspace is needed) */
+DW_API int dw_project3d_bwd(int32_t B, int32_t H, int32_t W, const float* points, const float* K,
+                            const float* T, float eps, const float* g_grid, float* g_points,
+                            float* g_T, void* workspace, size_t workspace_bytes, void* stream);
+
+/* grid_sample(src (B,C,H,W), grid (B,Ho,Wo,2), bilinear, border, align_corners=true) */
+DW_API int dw_warp_fwd(int32_t B, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                       const float* src, const float* grid, float* out, void* stream);
+/* gradient w.r.t. the grid only (colour images carry no gradient on this path) */
+DW_API int dw_warp_bwd(int32_t B, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                       const float* src, const float* grid, const float* g_out, float* g_grid,
+                       void* stream);
+
+/* clamp((1 - SSIM_3x3(x, y)) / 2, 0, 1) on `planes` = B*C independent H x W maps */
+DW_API int dw_ssim_fwd(int32_t planes, int32_t H, int32_t W, const float* x, const float* y,
+                       float* out, void* stream);
+/* g_x and/or g_y out (either may be NULL) */
+DW_API int dw_ssim_bwd(int32_t planes, int32_t H, int32_t W, const float* x, const float* y,
+                       const float* g_out, float* g_x, float* g_y, void* stream);
+
+/* edge-aware smoothness of disp (B,1,H,W) against img (B,3,H,W): out[0] scalar */
+DW_API size_t dw_smooth_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
+DW_API int dw_smooth_loss_fwd(int32_t B, int32_t H, int32_t W, const float* disp, const float* img,
+                              float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* g_loss: device scalar; g_disp (B,1,H,W) out */
+DW_API int dw_smooth_loss_bwd(int32_t B, int32_t H, int32_t W, const float* disp, const float* img,
+                              const float* g_loss, float* g_disp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

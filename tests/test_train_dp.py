@@ -1,0 +1,70 @@
+"""Data-parallel loop on CPU with gloo, world size 2: the all-reduced gradient
+bucket of two half-batch ranks equals the single-process full-batch gradient,
+and both ranks hold identical weights after the step.  The loss is injected
+(the CPU oracle): the shipped loss runs on GPUs only."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from depth_estimation_amd.synth import make_sequence
+from depth_estimation_amd.train import Trainer, shard
+
+H, W, B = 32, 64, 4
+
+
+def _oracle_loss(disp, color, pyr, K, inv_K, T, tie):
+    from oracle import photometric as ph
+    return ph.photometric_stack(disp, color, pyr, K, inv_K, T, tie)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)
+        seq = shard(make_sequence(B, H, W, seed=1), rank, world)
+        loss = tr.step(seq)
+        w = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params])
+        # plain numpy payloads: torch tensors would travel as shared-memory handles that die with the worker
+        out.put((rank, float(loss), tr.bucket.flat[:-1].numpy().copy(), w.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_full_batch():
+    torch.set_num_threads(4)
+    ref = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)
+    full = make_sequence(B, H, W, seed=1)
+    ref_loss = ref.step(full)
+    ref_grad = ref.bucket.flat[:-1].clone()
+    ref_w = torch.cat([p.detach().reshape(-1) for p in ref.bucket.params])
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, l0, g0, w0), (_, l1, g1, w1) = [(r, l, torch.from_numpy(g), torch.from_numpy(w)) for r, l, g, w in res]
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(w0, w1)
+    # per-rank means of equal shards average to the full-batch mean (photometric terms); the
+    # smoothness term's per-image normalisation makes this exact as well
+    assert abs(l0 - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    rel = float((g0 - ref_grad).abs().max() / ref_grad.abs().max())
+    assert rel <= 1e-3, rel
+    assert float(ref_grad.abs().max()) > 0
+    assert float((w0 - ref_w).abs().max()) <= 1e-4
+
+
+def test_trainer_without_gpu_needs_explicit_loss():
+    from depth_estimation_amd._lib import DepthwarpError
+    with pytest.raises(DepthwarpError):
+        Trainer("cpu")
