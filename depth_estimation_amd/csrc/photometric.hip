@@ -860,32 +860,44 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
 }
 
 // ------------------------------------------------- scalar loss
-// One block; wave w (of 16) reduces one of the 3*S sums, in double, in a fixed order.
+// One block of 1024 threads. Each of the 3*S sums (tile losses, smoothness x, y)
+// is accumulated in double by all threads (strided, several loads in flight),
+// reduced per wave with shuffles and across waves by one thread: fixed order.
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p, float* loss_out) {
-  __shared__ double s_sum[3 * DW_MAX_SCALES];
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  __shared__ double s_part[3 * DW_MAX_SCALES][1024 / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const int ntile = p.B * p.tilesX * p.tilesY;
-  if (wid < 3 * p.S) {
-    const int s = wid / 3, kind = wid - 3 * s;
-    double a = 0.0;
-    if (kind == 0) {
-      for (int t = lane; t < ntile; t += kWave) a += (double)p.tile_loss[(long)t * DW_MAX_SCALES + s];
-    } else {
-      for (int k = p.L.blk_off[s] + lane; k < p.L.blk_off[s + 1]; k += kWave)
-        a += (double)p.sm_part[(long)k * 3 + (kind - 1)];
+  for (int s = 0; s < p.S; ++s) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
+    for (int t = tid; t < ntile; t += 1024) a0 += (double)p.tile_loss[(long)t * DW_MAX_SCALES + s];
+#pragma unroll 2
+    for (int k = p.L.blk_off[s] + tid; k < p.L.blk_off[s + 1]; k += 1024) {
+      a1 += (double)p.sm_part[(long)k * 3 + 0];
+      a2 += (double)p.sm_part[(long)k * 3 + 1];
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
-    if (lane == 0) s_sum[wid] = a;
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_down(a0, off, kWave);
+      a1 += __shfl_down(a1, off, kWave);
+      a2 += __shfl_down(a2, off, kWave);
+    }
+    if (lane == 0) {
+      s_part[3 * s + 0][wid] = a0;
+      s_part[3 * s + 1][wid] = a1;
+      s_part[3 * s + 2][wid] = a2;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     double total = 0.0;
     for (int s = 0; s < p.S; ++s) {
+      double sum[3] = {0.0, 0.0, 0.0};
+      for (int k = 0; k < 3; ++k)
+        for (int w = 0; w < 1024 / kWave; ++w) sum[k] += s_part[3 * s + k][w];
       const int hs = p.L.Hs[s], ws = p.L.Ws[s];
-      const double photo = s_sum[3 * s] / ((double)p.B * p.H * p.W);
-      const double sm = s_sum[3 * s + 1] / ((double)p.B * hs * (ws - 1)) +
-                        s_sum[3 * s + 2] / ((double)p.B * (hs - 1) * ws);
+      const double photo = sum[0] / ((double)p.B * p.H * p.W);
+      const double sm = sum[1] / ((double)p.B * hs * (ws - 1)) + sum[2] / ((double)p.B * (hs - 1) * ws);
       loss_out[1 + s] = (float)photo;
       loss_out[1 + p.S + s] = (float)sm;
       total += photo + (double)kWSmooth * sm / (double)(1 << s);
