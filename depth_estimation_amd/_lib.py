@@ -56,6 +56,8 @@ _SIGNATURES = {
     "dw_smooth_loss_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "dw_smooth_loss_fwd": (C.c_int, [C.c_int32] * 3 + [_VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "dw_smooth_loss_bwd": (C.c_int, [C.c_int32] * 3 + [_VP, _VP, _VP, _VP, _VP]),
+    "dw_soft_argmin_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP]),
+    "dw_soft_argmin_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP]),
 }
 
 

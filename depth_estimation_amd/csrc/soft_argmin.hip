@@ -1,0 +1,227 @@
+// Fused double-softmax + soft-argmin disparity regression, forward and backward.
+//
+// Reference: /root/reference/model/model.py:454-456 (view to (1, D, H, W),
+// prob = softmax(-out, 1)) and :417-429 (squeeze, softmax(-prob, 0) AGAIN,
+// sum_d d * p).  The second softmax of an already normalised volume is a quirk
+// of the reference and is kept.  The reference streams the D x H x W volume
+// six to eight times (neg, softmax, squeeze, neg, softmax, mul with a
+// materialised d-grid, sum); here it is read from HBM exactly once per pass:
+//
+//   block = NW waves x 64 lanes; a lane owns VEC consecutive pixels, wave w owns
+//   the disparities [w*DPW, (w+1)*DPW) of those pixels and keeps its DPW*VEC
+//   cost values in registers.  The soft-max statistics (max, sum; then the two
+//   sums of the second soft-max) are combined across the NW waves through LDS.
+//   For fixed d the lanes of a wave read 64*VEC consecutive floats: coalesced.
+//
+// Backward recomputes the forward from the registers (nothing is saved) and
+// adds one more cross-wave sum:  with p1 = softmax(-x), p2 = softmax(-p1),
+// out = sum_d d p2_d:   dp1_d = -g p2_d (d - out);  dx_d = -p1_d (dp1_d - sum_k dp1_k p1_k).
+#include "dw_common.h"
+
+namespace dw {
+
+constexpr int SA_NW = 8;    // waves per block
+constexpr int SA_DPW = 32;  // disparities per wave -> up to 256 per pixel in registers
+constexpr int SA_NT = SA_NW * kWave;
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> { using type = float; };
+template <>
+struct VecT<2> { using type = float2; };
+template <>
+struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float* v) {
+  using T = typename VecT<VEC>::type;
+  const T t = *reinterpret_cast<const T*>(p);
+  const float* f = reinterpret_cast<const float*>(&t);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = f[i];
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float* v) {
+  using T = typename VecT<VEC>::type;
+  T t;
+  float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) f[i] = v[i];
+  *reinterpret_cast<T*>(p) = t;
+}
+
+// Combine one value per (wave, pixel) over the NW waves. `buf` is [NW][64*VEC].
+template <int VEC, bool IS_MAX>
+__device__ __forceinline__ void cross_wave(float* buf, int wid, int lane, float* v) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) buf[wid * (kWave * VEC) + lane * VEC + i] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float a = buf[lane * VEC + i];
+#pragma unroll
+    for (int w = 1; w < SA_NW; ++w) {
+      const float t = buf[w * (kWave * VEC) + lane * VEC + i];
+      a = IS_MAX ? fmaxf(a, t) : a + t;
+    }
+    v[i] = a;
+  }
+}
+
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, const float* __restrict__ x,
+                                                               const float* __restrict__ g_out,
+                                                               float* __restrict__ out,
+                                                               float* __restrict__ g_x) {
+  __shared__ float s_buf[BWD ? 5 : 4][SA_NW * kWave * VEC];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int b = blockIdx.y;
+  const long n0 = ((long)blockIdx.x * kWave + lane) * VEC;  // first pixel of this lane
+  const bool act = n0 < N;                                  // N % VEC == 0 is checked on the host
+  const float* xb = x + (long)b * D * N;
+  const int d0 = wid * SA_DPW;
+
+  // z = -x for this wave's disparities; missing ones behave as -inf
+  float z[SA_DPW][VEC];
+  float m[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SA_DPW; ++k) {
+    const int d = d0 + k;
+    if (act && d < D) {
+      float v[VEC];
+      load_vec<VEC>(xb + (long)d * N + n0, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        z[k][i] = -v[i];
+        m[i] = fmaxf(m[i], z[k][i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) z[k][i] = -INFINITY;
+    }
+  }
+  cross_wave<VEC, true>(s_buf[0], wid, lane, m);
+  if (!act) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m[i] = 0.f;  // keeps the arithmetic below finite on idle lanes
+  }
+  // first soft-max: e1 = exp(z - m), Z1 = sum e1
+  float zsum[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) zsum[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < SA_DPW; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      z[k][i] = __expf(z[k][i] - m[i]);  // exp(-inf) = 0 for missing disparities
+      zsum[i] += z[k][i];
+    }
+  cross_wave<VEC, false>(s_buf[1], wid, lane, zsum);
+  float inv1[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) inv1[i] = act ? 1.0f / zsum[i] : 0.f;
+  // second soft-max over -p1 (p1 in [0,1]: no shift needed), soft arg-min
+  float s2[VEC], n2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s2[i] = n2[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < SA_DPW; ++k) {
+    const bool have = (d0 + k) < D;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float p1 = z[k][i] * inv1[i];
+      const float e2 = have ? __expf(-p1) : 0.f;
+      z[k][i] = p1;  // keep p1; e2 is recomputed in the backward pass
+      s2[i] += e2;
+      n2[i] = fmaf((float)(d0 + k), e2, n2[i]);
+    }
+  }
+  cross_wave<VEC, false>(s_buf[2], wid, lane, s2);
+  cross_wave<VEC, false>(s_buf[3], wid, lane, n2);
+  float res[VEC], inv2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    inv2[i] = act ? 1.0f / s2[i] : 0.f;
+    res[i] = n2[i] * inv2[i];
+  }
+  if (!BWD) {
+    if (act && wid == 0) store_vec<VEC>(out + (long)b * N + n0, res);
+    return;
+  }
+  // backward
+  float g[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+  if (act) load_vec<VEC>(g_out + (long)b * N + n0, g);
+  float t[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) t[i] = 0.f;
+  // dp1_d = -g p2_d (d - out);  T = sum_d dp1_d p1_d
+#pragma unroll
+  for (int k = 0; k < SA_DPW; ++k) {
+    const bool have = (d0 + k) < D;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float p1 = z[k][i];
+      const float p2 = have ? __expf(-p1) * inv2[i] : 0.f;
+      const float dp1 = -g[i] * p2 * ((float)(d0 + k) - res[i]);
+      t[i] = fmaf(dp1, p1, t[i]);
+    }
+  }
+  cross_wave<VEC, false>(s_buf[4], wid, lane, t);
+  float* gb = g_x + (long)b * D * N;
+#pragma unroll
+  for (int k = 0; k < SA_DPW; ++k) {
+    const int d = d0 + k;
+    if (act && d < D) {
+      float v[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float p1 = z[k][i];
+        const float p2 = __expf(-p1) * inv2[i];
+        const float dp1 = -g[i] * p2 * ((float)d - res[i]);
+        v[i] = -p1 * (dp1 - t[i]);
+      }
+      store_vec<VEC>(gb + (long)d * N + n0, v);
+    }
+  }
+}
+
+template <bool BWD>
+static int launch_soft_argmin(int B, int D, long N, const float* x, const float* g_out, float* out,
+                              float* g_x, hipStream_t st) {
+  // widest vector the plane stride and the pointers allow
+  auto aligned = [&](int bytes) {
+    const uintptr_t m = bytes - 1;
+    return (((uintptr_t)x & m) | ((uintptr_t)out & m) | ((uintptr_t)g_out & m) | ((uintptr_t)g_x & m)) == 0;
+  };
+  if (N % 2 == 0 && aligned(8)) {
+    const dim3 grid((unsigned)((N / 2 + kWave - 1) / kWave), B);
+    soft_argmin_kernel<2, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
+  } else {
+    const dim3 grid((unsigned)((N + kWave - 1) / kWave), B);
+    soft_argmin_kernel<1, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
+  }
+  return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
+}
+
+}  // namespace dw
+
+using namespace dw;
+
+extern "C" int dw_soft_argmin_fwd(int32_t B, int32_t D, int64_t N, const float* cost, float* disp,
+                                  void* stream) {
+  if (!cost || !disp) return DW_ERR_NULL;
+  if (B < 1 || B > 65535 || D < 1 || D > SA_NW * SA_DPW || N < 1) return DW_ERR_SHAPE;
+  return launch_soft_argmin<false>(B, D, N, cost, nullptr, disp, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int dw_soft_argmin_bwd(int32_t B, int32_t D, int64_t N, const float* cost,
+                                  const float* g_disp, float* g_cost, void* stream) {
+  if (!cost || !g_disp || !g_cost) return DW_ERR_NULL;
+  if (B < 1 || B > 65535 || D < 1 || D > SA_NW * SA_DPW || N < 1) return DW_ERR_SHAPE;
+  return launch_soft_argmin<true>(B, D, N, cost, g_disp, nullptr, g_cost, (hipStream_t)stream);
+}

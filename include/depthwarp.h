@@ -189,6 +189,20 @@ DW_API int dw_smooth_loss_fwd(int32_t B, int32_t H, int32_t W, const float* disp
 DW_API int dw_smooth_loss_bwd(int32_t B, int32_t H, int32_t W, const float* disp, const float* img,
                               const float* g_loss, float* g_disp, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Soft-argmin disparity regression: the tail of DepthBlock.forward,
+ * /root/reference/model/model.py:454-456 and :417-429 --
+ *   prob = softmax(-cost, D); prob2 = softmax(-prob, D); disp = sum_d d * prob2[d]
+ * (the second soft-max of the normalised volume is the reference's own).
+ *   cost    (B, D, N) float32, D <= 256 disparities, N = H*W pixels per plane
+ *   disp    (B, N) out
+ * Backward: g_cost (B, D, N) out from g_disp (B, N); nothing saved by forward.
+ * ------------------------------------------------------------------------- */
+DW_API int dw_soft_argmin_fwd(int32_t B, int32_t D, int64_t N, const float* cost, float* disp,
+                              void* stream);
+DW_API int dw_soft_argmin_bwd(int32_t B, int32_t D, int64_t N, const float* cost,
+                              const float* g_disp, float* g_cost, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
