@@ -41,10 +41,13 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--batch", type=int, default=4)
     args = ap.parse_args()
     from depth_estimation_amd._lib import lib
     torch.cuda.set_device(0)
-    B, D, H, W = 4, 256, 192, 640
+    B, D, H, W = args.batch, 256, args.height, args.width
     N = H * W
     cost = torch.randn(B, D, H, W, device="cuda")
     disp = torch.empty(B, 1, H, W, device="cuda")

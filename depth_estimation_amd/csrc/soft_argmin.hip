@@ -20,9 +20,19 @@
 
 namespace dw {
 
-constexpr int SA_NW = 8;    // waves per block
-constexpr int SA_DPW = 32;  // disparities per wave -> up to 256 per pixel in registers
+constexpr int SA_NW = 16;   // waves per block
+constexpr int SA_DPW = 16;  // disparities per wave -> up to 256 per pixel in registers
 constexpr int SA_NT = SA_NW * kWave;
+constexpr float kLog2e = 1.4426950408889634f;
+// 2^x on the hardware exponential unit (arguments here are <= 0 and far from
+// the denormal range that the library wrapper would rescale for)
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifndef SA_MINW
+#define SA_MINW 8
+#endif
+#ifndef SA_VEC
+#define SA_VEC 2
+#endif
 
 template <int VEC>
 struct VecT;
@@ -70,7 +80,7 @@ __device__ __forceinline__ void cross_wave(float* buf, int wid, int lane, float*
 }
 
 template <int VEC, bool BWD>
-__global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, const float* __restrict__ x,
+__global__ __launch_bounds__(SA_NT, BWD ? 4 : SA_MINW) void soft_argmin_kernel(int D, long N, const float* __restrict__ x,
                                                                const float* __restrict__ g_out,
                                                                float* __restrict__ out,
                                                                float* __restrict__ g_x) {
@@ -82,25 +92,24 @@ __global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, co
   const float* xb = x + (long)b * D * N;
   const int d0 = wid * SA_DPW;
 
-  // z = -x for this wave's disparities; missing ones behave as -inf
+  // z = -x * log2(e) for this wave's disparities (soft-max in base 2); missing ones behave as -inf
   float z[SA_DPW][VEC];
   float m[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
+  // every load is issued unconditionally (clamped address) so that all of them
+  // are in flight together; masking happens on the values
+  const long n_safe = act ? n0 : 0;
 #pragma unroll
   for (int k = 0; k < SA_DPW; ++k) {
     const int d = d0 + k;
-    if (act && d < D) {
-      float v[VEC];
-      load_vec<VEC>(xb + (long)d * N + n0, v);
+    float v[VEC];
+    load_vec<VEC>(xb + (long)min(d, D - 1) * N + n_safe, v);
+    const bool have = act && d < D;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        z[k][i] = -v[i];
-        m[i] = fmaxf(m[i], z[k][i]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) z[k][i] = -INFINITY;
+    for (int i = 0; i < VEC; ++i) {
+      z[k][i] = have ? v[i] * -kLog2e : -INFINITY;
+      m[i] = fmaxf(m[i], z[k][i]);
     }
   }
   cross_wave<VEC, true>(s_buf[0], wid, lane, m);
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, co
   for (int k = 0; k < SA_DPW; ++k)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      z[k][i] = __expf(z[k][i] - m[i]);  // exp(-inf) = 0 for missing disparities
+      z[k][i] = exp2_fast(z[k][i] - m[i]);  // 2^-inf = 0 for missing disparities
       zsum[i] += z[k][i];
     }
   cross_wave<VEC, false>(s_buf[1], wid, lane, zsum);
@@ -133,8 +142,8 @@ __global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, co
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float p1 = z[k][i] * inv1[i];
-      const float e2 = have ? __expf(-p1) : 0.f;
-      z[k][i] = p1;  // keep p1; e2 is recomputed in the backward pass
+      const float e2 = have ? exp2_fast(p1 * -kLog2e) : 0.f;
+      if (BWD) z[k][i] = p1;  // keep p1; e2 is recomputed in the backward pass
       s2[i] += e2;
       n2[i] = fmaf((float)(d0 + k), e2, n2[i]);
     }
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, co
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float p1 = z[k][i];
-      const float p2 = have ? __expf(-p1) * inv2[i] : 0.f;
+      const float p2 = have ? exp2_fast(p1 * -kLog2e) * inv2[i] : 0.f;
       const float dp1 = -g[i] * p2 * ((float)(d0 + k) - res[i]);
       t[i] = fmaf(dp1, p1, t[i]);
     }
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(SA_NT, 2) void soft_argmin_kernel(int D, long N, co
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float p1 = z[k][i];
-        const float p2 = __expf(-p1) * inv2[i];
+        const float p2 = exp2_fast(p1 * -kLog2e) * inv2[i];
         const float dp1 = -g[i] * p2 * ((float)d - res[i]);
         v[i] = -p1 * (dp1 - t[i]);
       }
@@ -198,9 +207,9 @@ static int launch_soft_argmin(int B, int D, long N, const float* x, const float*
     const uintptr_t m = bytes - 1;
     return (((uintptr_t)x & m) | ((uintptr_t)out & m) | ((uintptr_t)g_out & m) | ((uintptr_t)g_x & m)) == 0;
   };
-  if (N % 2 == 0 && aligned(8)) {
-    const dim3 grid((unsigned)((N / 2 + kWave - 1) / kWave), B);
-    soft_argmin_kernel<2, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
+  if (N % SA_VEC == 0 && aligned(4 * SA_VEC)) {
+    const dim3 grid((unsigned)((N / SA_VEC + kWave - 1) / kWave), B);
+    soft_argmin_kernel<SA_VEC, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
   } else {
     const dim3 grid((unsigned)((N + kWave - 1) / kWave), B);
     soft_argmin_kernel<1, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
