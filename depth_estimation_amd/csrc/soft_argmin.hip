@@ -20,18 +20,28 @@
 
 namespace dw {
 
-constexpr int SA_NW = 16;   // waves per block
-constexpr int SA_DPW = 16;  // disparities per wave -> up to 256 per pixel in registers
+#ifndef SA_NW_
+#define SA_NW_ 8
+#endif
+constexpr int SA_NW = SA_NW_;   // waves per block
+constexpr int SA_DPW = 256 / SA_NW;  // disparities per wave -> up to 256 per pixel in registers
 constexpr int SA_NT = SA_NW * kWave;
 constexpr float kLog2e = 1.4426950408889634f;
 // 2^x on the hardware exponential unit (arguments here are <= 0 and far from
 // the denormal range that the library wrapper would rescale for)
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 #ifndef SA_MINW
-#define SA_MINW 8
+#define SA_MINW 2
 #endif
+#ifndef SA_MINW_B
+#define SA_MINW_B 2
+#endif
+// pixels per lane: forward (fewer live values) takes 16-byte loads, backward 8-byte ones
 #ifndef SA_VEC
-#define SA_VEC 2
+#define SA_VEC 4
+#endif
+#ifndef SA_VEC_B
+#define SA_VEC_B 2
 #endif
 
 template <int VEC>
@@ -80,7 +90,7 @@ __device__ __forceinline__ void cross_wave(float* buf, int wid, int lane, float*
 }
 
 template <int VEC, bool BWD>
-__global__ __launch_bounds__(SA_NT, BWD ? 4 : SA_MINW) void soft_argmin_kernel(int D, long N, const float* __restrict__ x,
+__global__ __launch_bounds__(SA_NT, BWD ? SA_MINW_B : SA_MINW) void soft_argmin_kernel(int D, long N, const float* __restrict__ x,
                                                                const float* __restrict__ g_out,
                                                                float* __restrict__ out,
                                                                float* __restrict__ g_x) {
@@ -97,18 +107,20 @@ __global__ __launch_bounds__(SA_NT, BWD ? 4 : SA_MINW) void soft_argmin_kernel(i
   float m[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) m[i] = -INFINITY;
-  // every load is issued unconditionally (clamped address) so that all of them
-  // are in flight together; masking happens on the values
+  // Every load is issued unconditionally (clamped address), all of them before
+  // the first use, so that they are in flight together; masking happens on the
+  // values.  The empty asm keeps the compiler from sinking a load into the
+  // conditional code that consumes it (which serialises the loads).
   const long n_safe = act ? n0 : 0;
 #pragma unroll
+  for (int k = 0; k < SA_DPW; ++k) load_vec<VEC>(xb + (long)min(d0 + k, D - 1) * N + n_safe, z[k]);
+#pragma unroll
   for (int k = 0; k < SA_DPW; ++k) {
-    const int d = d0 + k;
-    float v[VEC];
-    load_vec<VEC>(xb + (long)min(d, D - 1) * N + n_safe, v);
-    const bool have = act && d < D;
+    const bool have = act && (d0 + k) < D;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      z[k][i] = have ? v[i] * -kLog2e : -INFINITY;
+      asm volatile("" : "+v"(z[k][i]));
+      z[k][i] = have ? z[k][i] * -kLog2e : -INFINITY;
       m[i] = fmaxf(m[i], z[k][i]);
     }
   }
@@ -207,9 +219,10 @@ static int launch_soft_argmin(int B, int D, long N, const float* x, const float*
     const uintptr_t m = bytes - 1;
     return (((uintptr_t)x & m) | ((uintptr_t)out & m) | ((uintptr_t)g_out & m) | ((uintptr_t)g_x & m)) == 0;
   };
-  if (N % SA_VEC == 0 && aligned(4 * SA_VEC)) {
-    const dim3 grid((unsigned)((N / SA_VEC + kWave - 1) / kWave), B);
-    soft_argmin_kernel<SA_VEC, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
+  constexpr int V = BWD ? SA_VEC_B : SA_VEC;
+  if (N % V == 0 && aligned(4 * V)) {
+    const dim3 grid((unsigned)((N / V + kWave - 1) / kWave), B);
+    soft_argmin_kernel<V, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
   } else {
     const dim3 grid((unsigned)((N + kWave - 1) / kWave), B);
     soft_argmin_kernel<1, BWD><<<grid, SA_NT, 0, st>>>(D, N, x, g_out, out, g_x);
