@@ -9,6 +9,12 @@ soft_argmin: the disparity regression at the end of DepthBlock.forward
 float32 cost volume, B = 4 (503 MB: larger than the 256 MiB Infinity Cache, so
 the reads come from HBM).  Algorithmic bytes: forward D*4 + 4 per pixel,
 backward 2*D*4 + 4 per pixel.
+
+cost_volume: DepthBlock.cost_volume (model.py:460-508) at the feature-map size
+of a 192 x 640 input (F = 32, h = 96, w = 320, D = 64), B = 2: two
+(B, 64, 128, 96, 320) volumes = 2 x 1.0 GB per sample.  Algorithmic bytes:
+forward = the two volumes written + the four maps read; backward = the two
+volume gradients read + the four map gradients written.
 """
 import argparse
 import json
@@ -44,9 +50,72 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--only", choices=["soft_argmin", "cost_volume"], default=None)
     args = ap.parse_args()
-    from depth_estimation_amd._lib import lib
     torch.cuda.set_device(0)
+    if args.only in (None, "soft_argmin"):
+        bench_soft_argmin(args)
+    if args.only in (None, "cost_volume"):
+        bench_cost_volume(args)
+
+
+def line(name, unit, units, ms, args, workload, kernel, nbytes):
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    return {"metric": f"{name} throughput", "value": units / (ms * 1e-3), "unit": unit, "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbps,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                         "traffic": None, "algorithmic_bytes": nbytes}}
+
+
+def cpu_time(fn, budget_s=10.0, max_n=10):
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s and n < max_n:
+        fn()
+        n += 1
+    return (time.perf_counter() - t0) / n, n
+
+
+def bench_cost_volume(args):
+    from depth_estimation_amd._lib import lib
+    B, F, D = 2, 32, 64
+    h, w = args.height // 2, args.width // 2
+    maps = [torch.randn(B, F, h, w, device="cuda") for _ in range(4)]
+    left = torch.empty(B, D, 4 * F, h, w, device="cuda")
+    right = torch.empty_like(left)
+    gmaps = [torch.empty_like(m) for m in maps]
+    st = torch.cuda.current_stream().cuda_stream
+    L = lib()
+
+    def fwd():
+        assert L.dw_cost_volume_fwd(B, F, h, w, D, *(m.data_ptr() for m in maps), left.data_ptr(),
+                                    right.data_ptr(), st) == 0
+
+    def bwd():  # the volumes just written stand in for their gradients
+        assert L.dw_cost_volume_bwd(B, F, h, w, D, left.data_ptr(), right.data_ptr(),
+                                    *(g.data_ptr() for g in gmaps), st) == 0
+
+    nbytes = 2 * left.numel() * 4 + 4 * maps[0].numel() * 4
+    wl = f"cost volume of four ({B},{F},{h},{w}) maps, D = {D}"
+    for name, fn, kern in (("cost_volume_fwd", fwd, "cost_volume_fwd_kernel"),
+                           ("cost_volume_bwd", bwd, "cost_volume_bwd_kernel")):
+        ms = timed(fn, args.steps, args.warmup)
+        out = line(name, "volume pairs/s", B, ms, args, wl, kern, nbytes)
+        if name == "cost_volume_fwd" and not args.no_cpu_baseline:
+            from oracle.cost_volume import cost_volume as ref
+            cm = [m[:1].cpu() for m in maps]
+            per, n = cpu_time(lambda: ref(*cm, maxdisp=D), max_n=5)
+            out["cpu_baseline"] = {"value": 1 / per, "unit": "volume pairs/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": f"{n} constructions for one sample"}
+        print(json.dumps(out), flush=True)
+
+
+def bench_soft_argmin(args):
+    from depth_estimation_amd._lib import lib
     B, D, H, W = args.batch, 256, args.height, args.width
     N = H * W
     cost = torch.randn(B, D, H, W, device="cuda")

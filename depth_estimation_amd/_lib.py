@@ -58,6 +58,8 @@ _SIGNATURES = {
     "dw_smooth_loss_bwd": (C.c_int, [C.c_int32] * 3 + [_VP, _VP, _VP, _VP, _VP]),
     "dw_soft_argmin_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP]),
     "dw_soft_argmin_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP]),
+    "dw_cost_volume_fwd": (C.c_int, [C.c_int32] * 5 + [_VP] * 7),
+    "dw_cost_volume_bwd": (C.c_int, [C.c_int32] * 5 + [_VP] * 7),
 }
 
 

@@ -203,6 +203,25 @@ DW_API int dw_soft_argmin_fwd(int32_t B, int32_t D, int64_t N, const float* cost
 DW_API int dw_soft_argmin_bwd(int32_t B, int32_t D, int64_t N, const float* cost,
                               const float* g_disp, float* g_cost, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Cost-volume construction: DepthBlock.cost_volume,
+ * /root/reference/model/model.py:460-508 (zero-fill shift + concatenate per
+ * disparity, then stack), batch-generalised.
+ *   imgl, imgr, carl, carr   (B, F, h, w)   feature maps (reference: F = 32)
+ *   left, right              (B, D, 4F, h, w) out (reference: D = maxdisp/2 = 64)
+ *     d == 0: left = [imgl, carl, imgr, carr]            right = [imgr, carr, imgl, carl]
+ *     d  > 0: left = [imgl, imgr(x-d), carl, carr(x-d)]  right = [imgr, imgl(x+d), carr, carl(x+d)]
+ *   (the differing channel order at d == 0 is the reference's own, model.py:471-472 vs 497-498)
+ * Backward: gradients of the four maps from the gradients of the two volumes
+ * (sums in ascending disparity order: reproducible run to run).
+ * ------------------------------------------------------------------------- */
+DW_API int dw_cost_volume_fwd(int32_t B, int32_t F, int32_t h, int32_t w, int32_t D,
+                              const float* imgl, const float* imgr, const float* carl,
+                              const float* carr, float* left, float* right, void* stream);
+DW_API int dw_cost_volume_bwd(int32_t B, int32_t F, int32_t h, int32_t w, int32_t D,
+                              const float* g_left, const float* g_right, float* g_imgl,
+                              float* g_imgr, float* g_carl, float* g_carr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
