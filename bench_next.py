@@ -50,13 +50,15 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--only", choices=["soft_argmin", "cost_volume"], default=None)
+    ap.add_argument("--only", choices=["soft_argmin", "cost_volume", "metrics"], default=None)
     args = ap.parse_args()
     torch.cuda.set_device(0)
     if args.only in (None, "soft_argmin"):
         bench_soft_argmin(args)
     if args.only in (None, "cost_volume"):
         bench_cost_volume(args)
+    if args.only in (None, "metrics"):
+        bench_metrics(args)
 
 
 def line(name, unit, units, ms, args, workload, kernel, nbytes):
@@ -78,6 +80,45 @@ def cpu_time(fn, budget_s=10.0, max_n=10):
         fn()
         n += 1
     return (time.perf_counter() - t0) / n, n
+
+
+def bench_metrics(args):
+    """Loss + rmse + extrema in one pass (train.py:272-343, 250-251), then normalize_image."""
+    from depth_estimation_amd._lib import lib
+    B, H, W = 12, args.height, args.width
+    gt = torch.rand(B, 1, H, W, device="cuda") * 80
+    pred = torch.rand(B, 1, H, W, device="cuda") + 1e-3
+    out = torch.empty(B, 8, device="cuda")
+    img = torch.empty_like(pred)
+    L = lib()
+    nb = L.dw_compute_loss_workspace_bytes(B, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fused():
+        assert L.dw_compute_loss_metrics_fwd(B, H, W, H, W, gt.data_ptr(), pred.data_ptr(), 1e-3, 128.0,
+                                             out.data_ptr(), ws.data_ptr(), nb, st) == 0
+        assert L.dw_normalize_image(B, H * W, pred.data_ptr(), out.data_ptr() + 20, 8, img.data_ptr(), None, 0,
+                                    st) == 0
+
+    ms = timed(fused, args.steps, args.warmup)
+    nbytes = B * H * W * (8 + 8)   # loss+metrics: two maps in; normalize: one in, one out
+    o = line("loss_and_metrics", "samples/s", B, ms, args,
+             f"compute_loss + rmse + extrema + normalize_image on ({B},1,{H},{W})", "compute_loss_tile_kernel",
+             nbytes)
+    if not args.no_cpu_baseline:
+        from oracle.compute_loss import compute_loss_terms
+        from oracle.metrics import compute_errors_one_side, normalize_image
+        g1, p1 = gt[:1].cpu(), pred[:1].cpu()
+
+        def ref():
+            compute_loss_terms(g1, p1)
+            compute_errors_one_side(g1, p1[:, 0], H, W)
+            normalize_image(p1)
+        per, n = cpu_time(ref, max_n=20)
+        o["cpu_baseline"] = {"value": 1 / per, "unit": "samples/s", "cores": torch.get_num_threads(),
+                             "kind": "port", "sample": f"{n} evaluations of one sample"}
+    print(json.dumps(o), flush=True)
 
 
 def bench_cost_volume(args):

@@ -41,6 +41,11 @@ _SIGNATURES = {
                                      _VP]),
     "dw_compute_loss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dw_compute_loss_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "dw_compute_loss_metrics_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, C.c_float, C.c_float, _VP, _VP,
+                                                            C.c_size_t, _VP]),
+    "dw_normalize_image_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "dw_normalize_image": (C.c_int, [C.c_int32, C.c_int64, _VP, _VP, C.c_int32, _VP, _VP, C.c_size_t, _VP]),
+    "dw_rmse": (C.c_int, [C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "dw_disp_to_depth_fwd": (C.c_int, [C.c_int64, _VP, C.c_float, C.c_float, _VP, _VP, _VP]),
     "dw_disp_to_depth_bwd": (C.c_int, [C.c_int64, _VP, _VP, _VP, C.c_float, _VP, _VP]),
     "dw_backproject_fwd": (C.c_int, [C.c_int32] * 3 + [_VP, _VP, _VP, _VP]),

@@ -14,6 +14,12 @@
 // SSIM follows kornia's definition: 7x7 Gaussian window (sigma 1.5, normalised),
 // reflect border, C1 = 0.01^2, C2 = 0.03^2, ssim = num / (den + 1e-12).  The
 // window is applied separably (rows, then columns) from an LDS tile.
+//
+// The METRICS variant adds, from the same tile, what the reference's evaluation
+// code derives from the same two tensors in separate passes:
+//   rmse = sqrt(mean((resize(gt) - clamp(1/pred, lo, hi))^2))    train.py:311-343
+//   min(pred), max(pred) for normalize_image                     train.py:248-253
+// and normalize_image itself is the element-wise kernel at the end of the file.
 #include "dw_common.h"
 
 namespace dw {
@@ -25,12 +31,33 @@ struct ClParams {
   int B, Ht, Wt, H, W, tilesX, tilesY;
   const float* target;
   const float* pred;
-  float* part;  // [B][tiles][4]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|
-  float* out;   // [B][4]
+  float* part;  // [B][tiles][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
+                //                       sum (t - clamp(1/p))^2, min p, max p, unused
+  float* out;   // [B][4 or 8]
   float g[7];   // Gaussian taps
+  float clamp_lo, clamp_hi;
 };
 
+// Minimum / maximum over a block (result in thread 0); `red` holds NT/64 floats.
+template <int NT, bool IS_MAX>
+__device__ __forceinline__ float block_extreme(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(v, off, kWave);
+    v = IS_MAX ? fmaxf(v, o) : fminf(v, o);
+  }
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NT / kWave; ++w) v = IS_MAX ? fmaxf(v, red[w]) : fminf(v, red[w]);
+  }
+  return v;
+}
+
+template <bool METRICS>
 __global__ __launch_bounds__(CL_NT) void compute_loss_tile_kernel(const ClParams p) {
+  constexpr int PS = METRICS ? 8 : 4;
   __shared__ float s_t[CL_R];              // resized target, reflect-mapped halo
   __shared__ float s_p[CL_R];              // prediction
   __shared__ float s_h[5][CL_RH * CL_TW];  // row-filtered t, p, tt, pp, tp
@@ -84,6 +111,7 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_tile_kernel(const ClParams
   __syncthreads();
 
   float sdx = 0.f, sdy = 0.f, sss = 0.f, sl1 = 0.f;
+  float sse = 0.f, pmin = INFINITY, pmax = -INFINITY;
   for (int i = tid; i < CL_TH * CL_TW; i += CL_NT) {
     const int cy = i / CL_TW, cx = i - cy * CL_TW;
     const int y = y00 + CL_HALO + cy, x = x00 + CL_HALO + cx;
@@ -118,8 +146,16 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_tile_kernel(const ClParams
     sdy += fabsf(dy);
     const int c = yc * CL_RW + xc;
     sl1 += fabsf(s_t[c] - s_p[c]);
+    if (METRICS) {
+      const float q = s_p[c];
+      const float depth = fminf(fmaxf(1.0f / q, p.clamp_lo), p.clamp_hi);
+      const float e = s_t[c] - depth;
+      sse = fmaf(e, e, sse);
+      pmin = fminf(pmin, q);
+      pmax = fmaxf(pmax, q);
+    }
   }
-  float* out = p.part + ((long)b * p.tilesX * p.tilesY + blockIdx.x) * 4;
+  float* out = p.part + ((long)b * p.tilesX * p.tilesY + blockIdx.x) * PS;
   float t = block_sum<CL_NT>(sdx, s_red);
   if (tid == 0) out[0] = t;
   t = block_sum<CL_NT>(sdy, s_red);
@@ -128,22 +164,44 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_tile_kernel(const ClParams
   if (tid == 0) out[2] = t;
   t = block_sum<CL_NT>(sl1, s_red);
   if (tid == 0) out[3] = t;
+  if (METRICS) {
+    t = block_sum<CL_NT>(sse, s_red);
+    if (tid == 0) out[4] = t;
+    t = block_extreme<CL_NT, false>(pmin, s_red);
+    if (tid == 0) out[5] = t;
+    t = block_extreme<CL_NT, true>(pmax, s_red);
+    if (tid == 0) out[6] = t;
+  }
 }
 
+template <bool METRICS>
 __global__ __launch_bounds__(256) void compute_loss_finalize_kernel(const ClParams p) {
-  __shared__ double red[4][256];
+  constexpr int PS = METRICS ? 8 : 4, NS = METRICS ? 5 : 4;  // partial stride, number of sums
+  __shared__ double red[NS][256];
+  __shared__ float ext[2][256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int nt = p.tilesX * p.tilesY;
-  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  double a[NS];
+  for (int k = 0; k < NS; ++k) a[k] = 0.0;
+  float lo = INFINITY, hi = -INFINITY;
   for (int t = tid; t < nt; t += 256) {
-    const float* src = p.part + ((long)b * nt + t) * 4;
-    for (int k = 0; k < 4; ++k) a[k] += (double)src[k];
+    const float* src = p.part + ((long)b * nt + t) * PS;
+    for (int k = 0; k < NS; ++k) a[k] += (double)src[k];
+    if (METRICS) {
+      lo = fminf(lo, src[5]);
+      hi = fmaxf(hi, src[6]);
+    }
   }
-  for (int k = 0; k < 4; ++k) red[k][tid] = a[k];
+  for (int k = 0; k < NS; ++k) red[k][tid] = a[k];
+  ext[0][tid] = lo;
+  ext[1][tid] = hi;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o)
-      for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + o];
+    if (tid < o) {
+      for (int k = 0; k < NS; ++k) red[k][tid] += red[k][tid + o];
+      ext[0][tid] = fminf(ext[0][tid], ext[0][tid + o]);
+      ext[1][tid] = fmaxf(ext[1][tid], ext[1][tid + o]);
+    }
     __syncthreads();
   }
   if (tid == 0) {
@@ -152,11 +210,126 @@ __global__ __launch_bounds__(256) void compute_loss_finalize_kernel(const ClPara
     const float smooth = mx * expf(mx) + my * expf(my);
     const float ssim_term = 1.f - (float)(red[2][0] / n);
     const float l1 = (float)(red[3][0] / n);
-    float* o = p.out + (long)b * 4;
+    float* o = p.out + (long)b * PS;
     o[0] = 0.75f * ssim_term + 0.20f * l1 + 0.15f * smooth;
     o[1] = ssim_term;
     o[2] = l1;
     o[3] = smooth;
+    if (METRICS) {
+      o[4] = sqrtf((float)(red[NS - 1][0] / n));
+      o[5] = ext[0][0];
+      o[6] = ext[1][0];
+      o[7] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- normalize_image
+constexpr int NI_NT = 256, NI_PER_BLOCK = 4096;
+
+// per-block minimum / maximum of x[b]: part[(b * nblk + blk) * 2 + {0, 1}]
+__global__ __launch_bounds__(NI_NT) void minmax_part_kernel(long n, int nblk, const float* __restrict__ x,
+                                                            float* __restrict__ part) {
+  __shared__ float red[NI_NT / kWave];
+  const int b = blockIdx.y;
+  const float* xb = x + (long)b * n;
+  float lo = INFINITY, hi = -INFINITY;
+  const long base = (long)blockIdx.x * NI_PER_BLOCK;
+#pragma unroll 4
+  for (int k = threadIdx.x; k < NI_PER_BLOCK; k += NI_NT) {
+    const long i = base + k;
+    if (i < n) {
+      const float v = xb[i];
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
+    }
+  }
+  lo = block_extreme<NI_NT, false>(lo, red);
+  hi = block_extreme<NI_NT, true>(hi, red);
+  if (threadIdx.x == 0) {
+    part[((long)b * nblk + blockIdx.x) * 2 + 0] = lo;
+    part[((long)b * nblk + blockIdx.x) * 2 + 1] = hi;
+  }
+}
+
+// sqrt(mean((a - b)^2)) per sample (compute_depth_errors, train.py:338-343):
+// per-block partial sums, then one block per sample adds them in double.
+__global__ __launch_bounds__(NI_NT) void sse_part_kernel(long n, int nblk, const float* __restrict__ a,
+                                                         const float* __restrict__ c,
+                                                         float* __restrict__ part) {
+  __shared__ float red[NI_NT / kWave];
+  const int b = blockIdx.y;
+  const float* ab = a + (long)b * n;
+  const float* cb = c + (long)b * n;
+  float acc = 0.f;
+  const long base = (long)blockIdx.x * NI_PER_BLOCK;
+#pragma unroll 4
+  for (int k = threadIdx.x; k < NI_PER_BLOCK; k += NI_NT) {
+    const long i = base + k;
+    if (i < n) {
+      const float e = ab[i] - cb[i];
+      acc = fmaf(e, e, acc);
+    }
+  }
+  const float t = block_sum<NI_NT>(acc, red);
+  if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(NI_NT) void rmse_finalize_kernel(long n, int nblk, const float* __restrict__ part,
+                                                              float* __restrict__ out) {
+  __shared__ double red[NI_NT];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double a = 0.0;
+  for (int k = tid; k < nblk; k += NI_NT) a += (double)part[(long)b * nblk + k];
+  red[tid] = a;
+  __syncthreads();
+  for (int o = NI_NT / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) out[b] = sqrtf((float)(red[0] / (double)n));
+}
+
+// out = (x - mi) / d,  d = ma - mi, or 1e5 if ma == mi (train.py:250-253).  The
+// reference takes ma and mi to the host as Python floats: d is their double
+// difference rounded to float32, and a division of a device tensor by a host
+// scalar is evaluated as a multiplication with the float32 reciprocal.
+__global__ __launch_bounds__(NI_NT) void normalize_image_kernel(long n, int nblk, const float* __restrict__ x,
+                                                                const float* __restrict__ part,
+                                                                const float* __restrict__ minmax,
+                                                                int minmax_stride, float* __restrict__ out) {
+  __shared__ float red[NI_NT / kWave];
+  __shared__ float s_mm[2];
+  const int b = blockIdx.y;
+  if (minmax) {
+    if (threadIdx.x == 0) {
+      s_mm[0] = minmax[(long)b * minmax_stride];
+      s_mm[1] = minmax[(long)b * minmax_stride + 1];
+    }
+  } else {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int k = threadIdx.x; k < nblk; k += NI_NT) {
+      lo = fminf(lo, part[((long)b * nblk + k) * 2 + 0]);
+      hi = fmaxf(hi, part[((long)b * nblk + k) * 2 + 1]);
+    }
+    lo = block_extreme<NI_NT, false>(lo, red);
+    hi = block_extreme<NI_NT, true>(hi, red);
+    if (threadIdx.x == 0) {
+      s_mm[0] = lo;
+      s_mm[1] = hi;
+    }
+  }
+  __syncthreads();
+  const float mi = s_mm[0], ma = s_mm[1];
+  const float d = (ma != mi) ? (float)((double)ma - (double)mi) : 1e5f;
+  const float inv = 1.0f / d;
+  const float* xb = x + (long)b * n;
+  float* ob = out + (long)b * n;
+  const long base = (long)blockIdx.x * NI_PER_BLOCK;
+#pragma unroll 4
+  for (int k = threadIdx.x; k < NI_PER_BLOCK; k += NI_NT) {
+    const long i = base + k;
+    if (i < n) ob[i] = (xb[i] - mi) * inv;
   }
 }
 
@@ -167,12 +340,13 @@ using namespace dw;
 extern "C" size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t W) {
   if (B < 1 || H < 4 || W < 4) return 0;
   const size_t tiles = (size_t)((W + CL_TW - 1) / CL_TW) * ((H + CL_TH - 1) / CL_TH);
-  return align_up(sizeof(float) * 4 * tiles * B, 256);
+  return align_up(sizeof(float) * 8 * tiles * B, 256);  // enough for the metrics variant too
 }
 
-extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                                   const float* target, const float* pred, float* out,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+template <bool METRICS>
+static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                               const float* target, const float* pred, float clamp_lo, float clamp_hi,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!target || !pred || !out || !workspace) return DW_ERR_NULL;
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
@@ -190,6 +364,8 @@ extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H,
   p.pred = pred;
   p.part = (float*)workspace;
   p.out = out;
+  p.clamp_lo = clamp_lo;
+  p.clamp_hi = clamp_hi;
   double g[7], sum = 0.0;
   for (int k = 0; k < 7; ++k) {
     const double x = k - 3;
@@ -198,7 +374,64 @@ extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H,
   }
   for (int k = 0; k < 7; ++k) p.g[k] = (float)(g[k] / sum);
   hipStream_t st = (hipStream_t)stream;
-  compute_loss_tile_kernel<<<dim3(p.tilesX * p.tilesY, B), CL_NT, 0, st>>>(p);
-  compute_loss_finalize_kernel<<<B, 256, 0, st>>>(p);
+  compute_loss_tile_kernel<METRICS><<<dim3(p.tilesX * p.tilesY, B), CL_NT, 0, st>>>(p);
+  compute_loss_finalize_kernel<METRICS><<<B, 256, 0, st>>>(p);
+  return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
+}
+
+extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                                   const float* target, const float* pred, float* out,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, workspace,
+                                    workspace_bytes, stream);
+}
+
+extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                                           const float* target, const float* pred, float clamp_min,
+                                           float clamp_max, float* out, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (!(clamp_min <= clamp_max)) return DW_ERR_ARG;
+  return compute_loss_launch<true>(B, Ht, Wt, H, W, target, pred, clamp_min, clamp_max, out, workspace,
+                                   workspace_bytes, stream);
+}
+
+extern "C" size_t dw_normalize_image_workspace_bytes(int32_t B, int64_t n) {
+  if (B < 1 || n < 1) return 0;
+  const size_t nblk = (size_t)((n + NI_PER_BLOCK - 1) / NI_PER_BLOCK);
+  return align_up(sizeof(float) * 2 * nblk * B, 256);
+}
+
+extern "C" int dw_rmse(int32_t B, int64_t n, const float* a, const float* b, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!a || !b || !out || !workspace) return DW_ERR_NULL;
+  if (B < 1 || B > 65535 || n < 1 || n > ((int64_t)1 << 40)) return DW_ERR_SHAPE;
+  const long nblk = (n + NI_PER_BLOCK - 1) / NI_PER_BLOCK;
+  if (nblk > 0x7fffffffL) return DW_ERR_SHAPE;
+  if (workspace_bytes < dw_normalize_image_workspace_bytes(B, n) || ((uintptr_t)workspace & 255))
+    return DW_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  sse_part_kernel<<<dim3((unsigned)nblk, B), NI_NT, 0, st>>>(n, (int)nblk, a, b, (float*)workspace);
+  rmse_finalize_kernel<<<B, NI_NT, 0, st>>>(n, (int)nblk, (const float*)workspace, out);
+  return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
+}
+
+extern "C" int dw_normalize_image(int32_t B, int64_t n, const float* x, const float* minmax,
+                                  int32_t minmax_stride, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!x || !out) return DW_ERR_NULL;
+  if (B < 1 || B > 65535 || n < 1 || n > ((int64_t)1 << 40)) return DW_ERR_SHAPE;
+  const long nblk = (n + NI_PER_BLOCK - 1) / NI_PER_BLOCK;
+  if (nblk > 0x7fffffffL) return DW_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (minmax) {
+    if (minmax_stride < 2) return DW_ERR_ARG;
+  } else {
+    if (!workspace) return DW_ERR_NULL;
+    if (workspace_bytes < dw_normalize_image_workspace_bytes(B, n) || ((uintptr_t)workspace & 255))
+      return DW_ERR_WORKSPACE;
+    minmax_part_kernel<<<dim3((unsigned)nblk, B), NI_NT, 0, st>>>(n, (int)nblk, x, (float*)workspace);
+  }
+  normalize_image_kernel<<<dim3((unsigned)nblk, B), NI_NT, 0, st>>>(n, (int)nblk, x, (const float*)workspace,
+                                                                    minmax, minmax_stride, out);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }

@@ -138,6 +138,37 @@ DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
                         const float* target, const float* pred, float* out,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same pass, additionally producing the evaluation metrics the reference
+ * computes from the same two tensors: Train.compute_errors /
+ * compute_depth_errors, train.py:311-343 (rmse between the resized ground
+ * truth and clamp(1/pred, clamp_min, clamp_max); the reference clamps to
+ * [1e-3, Config.maxdisp]), and the extrema normalize_image needs
+ * (train.py:250-251).
+ *   out      (B,8) floats: loss, ssim_term, l1, smooth, rmse, pred_min, pred_max, 0
+ */
+DW_API int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                                const float* target, const float* pred, float clamp_min,
+                                float clamp_max, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
+/* Train.normalize_image, train.py:248-253, per sample and without the two
+ * host round trips of the reference: out = (x - min) / (max - min), with 1e5 as
+ * the divisor when max == min.
+ *   x, out   (B, n)
+ *   minmax   NULL (extrema are computed here; needs the workspace), or device
+ *            floats with min at [b*minmax_stride] and max at [b*minmax_stride+1]
+ *            (e.g. out + 5 of the call above with stride 8; workspace unused)
+ */
+DW_API size_t dw_normalize_image_workspace_bytes(int32_t B, int64_t n);
+DW_API int dw_normalize_image(int32_t B, int64_t n, const float* x, const float* minmax,
+                              int32_t minmax_stride, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Train.compute_depth_errors, train.py:338-343: out[b] = sqrt(mean((a - b)^2))
+ * over the n elements of sample b.  Workspace: dw_normalize_image_workspace_bytes(B, n). */
+DW_API int dw_rmse(int32_t B, int64_t n, const float* a, const float* b, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Unfused building blocks (absent from the reference; the module interfaces
  * of the public view-synthesis formulation).  Same arithmetic as the fused

@@ -1,0 +1,83 @@
+"""GPU parity of the evaluation metrics (train.py:248-253, 311-343) against
+their restatement.  Floating point: 1e-5 relative on the rmse, 1e-6 on the
+normalised image (element-wise, one rounding apart at most), extrema exact."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(B, Ht, Wt, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(B, 1, Ht, Wt, generator=g) * 80.0
+    pred = torch.rand(B, H, W, generator=g) * 0.5 + 1e-4    # 1/pred crosses the upper clamp
+    return gt, pred
+
+
+@pytest.mark.parametrize("B,Ht,Wt,H,W", [(1, 375, 1242, 64, 128), (2, 48, 96, 48, 96), (3, 37, 53, 20, 68)])
+def test_fused_metrics_match_restatement(B, Ht, Wt, H, W):
+    from depth_estimation_amd.metrics import compute_loss_and_metrics
+    from depth_estimation_amd.loss import compute_loss_terms
+    from oracle.metrics import compute_errors_one_side
+    gt, pred = _pair(B, Ht, Wt, H, W, seed=H)
+    want = compute_errors_one_side(gt, pred, H, W)
+    m = compute_loss_and_metrics(gt.cuda(), pred.cuda())
+    assert torch.allclose(m["rmse"].cpu(), want, rtol=1e-5)
+    assert torch.equal(m["pred_min"].cpu(), pred.flatten(1).min(1).values)
+    assert torch.equal(m["pred_max"].cpu(), pred.flatten(1).max(1).values)
+    # the loss columns are those of the plain loss call
+    t = compute_loss_terms(gt.cuda(), pred.cuda())
+    for k in ("loss", "ssim_term", "l1", "smooth"):
+        assert torch.equal(m[k], t[k])
+
+
+def test_compute_errors_call_shape():
+    from depth_estimation_amd.metrics import compute_errors
+    from oracle.metrics import compute_errors_one_side
+    gl, pl = _pair(1, 50, 70, 32, 64, seed=1)
+    gr, pr = _pair(1, 50, 70, 32, 64, seed=2)
+    l, r = compute_errors({"l_depth": gl.cuda().double(), "r_depth": gr.cuda().double()},
+                          {"l_pred": pl.cuda(), "r_pred": pr.cuda()})
+    assert l.dim() == 0 and r.dim() == 0
+    assert torch.allclose(l.cpu(), compute_errors_one_side(gl, pl, 32, 64)[0], rtol=1e-5)
+    assert torch.allclose(r.cpu(), compute_errors_one_side(gr, pr, 32, 64)[0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 192, 640), (4, 1, 33, 65), (2, 5000)])
+def test_compute_depth_errors(shape):
+    from depth_estimation_amd.metrics import compute_depth_errors
+    from oracle.metrics import compute_depth_errors as ref
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(shape, generator=g) * 10, torch.rand(shape, generator=g) * 10
+    got = compute_depth_errors(a.cuda(), b.cuda())
+    want = ref(a, b)
+    assert torch.allclose(got.cpu().reshape(-1), want, rtol=1e-5)
+    z = compute_depth_errors(a.cuda(), a.cuda())
+    assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(1, 192, 640), (3, 17, 29), (2, 4097)])
+def test_normalize_image(shape):
+    from depth_estimation_amd.metrics import normalize_image
+    from oracle.metrics import normalize_image as ref
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(shape, generator=g) * 37.0 + 5.0
+    got = normalize_image(x.cuda()).cpu()
+    want = ref(x)
+    assert got.shape == x.shape
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    flat = got.flatten(1)
+    assert torch.equal(flat.min(1).values, torch.zeros(shape[0]))
+    assert float((flat.max(1).values - 1).abs().max()) <= 1e-6
+    # known extrema handed over: same result
+    mm = torch.stack([x.flatten(1).min(1).values, x.flatten(1).max(1).values], 1).cuda()
+    assert torch.equal(normalize_image(x.cuda(), mm).cpu(), got)
+
+
+def test_normalize_constant_image_uses_1e5():
+    from depth_estimation_amd.metrics import normalize_image
+    x = torch.full((2, 8, 8), 3.0)
+    x[1, 0, 0] = 5.0
+    got = normalize_image(x.cuda()).cpu()
+    assert float(got[0].abs().max()) == 0.0            # (x - mi) / 1e5 with x == mi
+    assert float(got[1].max()) == 1.0 and float(got[1].min()) == 0.0

@@ -38,3 +38,16 @@ def test_soft_argmin_closed_form():
     p2 = torch.softmax(-torch.tensor([0.0, 1.0, 0.0, 0.0]), 0)
     want = float((p2 * torch.arange(4.0)).sum())
     assert abs(float(soft_argmin(c)) - want) < 1e-6
+
+
+def test_metrics_closed_form():
+    from oracle.metrics import compute_depth_errors, compute_errors_one_side, normalize_image
+    gt = torch.full((2, 1, 4, 6), 3.0)
+    pred = torch.full((2, 4, 6), 0.5)            # 1/pred = 2 -> error 1 everywhere
+    pred[1] = 1e-6                               # 1/pred = 1e6 -> clamped to maxdisp
+    r = compute_errors_one_side(gt, pred, 4, 6, maxdisp=128.0)
+    assert torch.allclose(r, torch.tensor([1.0, 125.0]))
+    assert torch.allclose(compute_depth_errors(torch.zeros(1, 5), torch.full((1, 5), 2.0)), torch.tensor([2.0]))
+    x = torch.tensor([[1.0, 3.0, 2.0], [4.0, 4.0, 4.0]])
+    n = normalize_image(x)
+    assert torch.equal(n[0], torch.tensor([0.0, 1.0, 0.5])) and torch.equal(n[1], torch.zeros(3))
