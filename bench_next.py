@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--only", choices=["soft_argmin", "cost_volume", "metrics"], default=None)
+    ap.add_argument("--only", choices=["soft_argmin", "cost_volume", "metrics", "lidar"], default=None)
     args = ap.parse_args()
     torch.cuda.set_device(0)
     if args.only in (None, "soft_argmin"):
@@ -59,6 +59,8 @@ def main():
         bench_cost_volume(args)
     if args.only in (None, "metrics"):
         bench_metrics(args)
+    if args.only in (None, "lidar"):
+        bench_lidar(args)
 
 
 def line(name, unit, units, ms, args, workload, kernel, nbytes):
@@ -118,6 +120,44 @@ def bench_metrics(args):
         per, n = cpu_time(ref, max_n=20)
         o["cpu_baseline"] = {"value": 1 / per, "unit": "samples/s", "cores": torch.get_num_threads(),
                              "kind": "port", "sample": f"{n} evaluations of one sample"}
+    print(json.dumps(o), flush=True)
+
+
+def bench_lidar(args):
+    """Velodyne projection + sparse depth map (load_dataset.py:116-148), 64 scans of 120k points."""
+    import numpy as np
+    from depth_estimation_amd._lib import lib
+    from depth_estimation_amd.lidar import KITTI_LIKE_CALIB, synthetic_scan, velo_to_image_matrix
+    B, n, H, W = 64, 120000, 375, 1242
+    P = velo_to_image_matrix(KITTI_LIKE_CALIB["cam2cam"], KITTI_LIKE_CALIB["velo2cam"], 2)
+    scan = synthetic_scan(n, seed=0)
+    pts = torch.from_numpy(scan)[None].repeat(B, 1, 1).cuda()
+    npts = torch.full((B,), n, dtype=torch.int32, device="cuda")
+    Pb = torch.from_numpy(P)[None].repeat(B, 1, 1).cuda()
+    pts_im = torch.zeros(B, n, 3, dtype=torch.float64, device="cuda")
+    n_valid = torch.empty(B, dtype=torch.int32, device="cuda")
+    depth = torch.empty(B, H, W, dtype=torch.float64, device="cuda")
+    L = lib()
+    nb = L.dw_lidar_workspace_bytes(B, n, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        assert L.dw_lidar_project(B, n, H, W, pts.data_ptr(), npts.data_ptr(), Pb.data_ptr(), 0, pts_im.data_ptr(),
+                                  n_valid.data_ptr(), depth.data_ptr(), ws.data_ptr(), nb, st) == 0
+
+    ms = timed(run, args.steps, args.warmup)
+    kept = int(n_valid.sum())
+    nbytes = B * n * 16 + kept * 24 + B * H * W * 8   # scan in, kept points out, depth map out
+    o = line("lidar_project", "scans/s", B, ms, args,
+             f"{B} scans x {n} points -> {H}x{W} sparse depth (float64), {kept // B} points kept per scan",
+             "lidar_depth_kernel", nbytes)
+    o["dtype"] = "f64"
+    if not args.no_cpu_baseline:
+        from oracle.lidar import project_scan
+        per, k = cpu_time(lambda: project_scan(scan, P, (H, W)), max_n=20)
+        o["cpu_baseline"] = {"value": 1 / per, "unit": "scans/s", "cores": 1, "kind": "port",
+                             "sample": f"{k} projections of one scan"}
     print(json.dumps(o), flush=True)
 
 

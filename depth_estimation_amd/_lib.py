@@ -63,6 +63,9 @@ _SIGNATURES = {
     "dw_smooth_loss_bwd": (C.c_int, [C.c_int32] * 3 + [_VP, _VP, _VP, _VP, _VP]),
     "dw_soft_argmin_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP]),
     "dw_soft_argmin_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP]),
+    "dw_lidar_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "dw_lidar_project": (C.c_int, [C.c_int32] * 4 + [_VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_size_t,
+                                                      _VP]),
     "dw_cost_volume_fwd": (C.c_int, [C.c_int32] * 5 + [_VP] * 7),
     "dw_cost_volume_bwd": (C.c_int, [C.c_int32] * 5 + [_VP] * 7),
 }

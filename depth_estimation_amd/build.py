@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libdepthwarp.so"
-SOURCES = ["photometric.hip", "compute_loss.hip", "modules.hip", "soft_argmin.hip", "cost_volume.hip", "abi.hip"]
+SOURCES = ["photometric.hip", "compute_loss.hip", "modules.hip", "soft_argmin.hip", "cost_volume.hip", "lidar.hip", "abi.hip"]
 HEADERS = [CSRC / "dw_common.h", ROOT / "include" / "depthwarp.h"]
 
 

@@ -253,6 +253,27 @@ DW_API int dw_cost_volume_bwd(int32_t B, int32_t F, int32_t h, int32_t w, int32_
                               const float* g_left, const float* g_right, float* g_imgl,
                               float* g_imgr, float* g_carl, float* g_carr, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Velodyne scan -> image plane: Dataset.generate_depth_map,
+ * /root/reference/dataset/load_dataset.py:116-148 (projection, in-bounds
+ * filter, nearest-depth map with the reference's duplicate handling), batched
+ * over scans and evaluated in float64 as NumPy does.  The Delaunay hole filling
+ * that follows in the reference (:151, :155-165) consumes `pts_im` on the host.
+ *   points    (B, n_max, 4) float32 rows (forward, left, up, reflectance), 16-byte aligned
+ *   n_points  (B) int32, device: rows in use per scan
+ *   P         (B, 3, 4) float64: P_rect . R_cam2rect . velo2cam  (:111-114)
+ *   vel_depth non-zero: z = forward instead of the projective depth (:125-126)
+ *   pts_im    (B, n_max, 3) float64 out: kept points (x, y, z) in scan order;
+ *             rows >= n_valid[b] are not written
+ *   n_valid   (B) int32 out, device
+ *   depth     (B, H, W) float64 out: the sparse map of :137-148
+ * ------------------------------------------------------------------------- */
+DW_API size_t dw_lidar_workspace_bytes(int32_t B, int32_t n_max, int32_t H, int32_t W);
+DW_API int dw_lidar_project(int32_t B, int32_t n_max, int32_t H, int32_t W, const float* points,
+                            const int32_t* n_points, const double* P, int32_t vel_depth,
+                            double* pts_im, int32_t* n_valid, double* depth, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+"""GPU parity of the velodyne projection / sparse depth map against the
+restated reference lines (load_dataset.py:116-148).  Everything is float64
+arithmetic in a fixed order and integer selection: compared bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _P(cam=2):
+    from depth_estimation_amd.lidar import KITTI_LIKE_CALIB, velo_to_image_matrix
+    return velo_to_image_matrix(KITTI_LIKE_CALIB["cam2cam"], KITTI_LIKE_CALIB["velo2cam"], cam)
+
+
+def _run(scans, P, shape, vel_depth=False):
+    from depth_estimation_amd.lidar import project_scans
+    B, n_max = len(scans), max(len(s) for s in scans)
+    pts = np.zeros((B, n_max, 4), np.float32)
+    for b, s in enumerate(scans):
+        pts[b, :len(s)] = s
+    n = torch.tensor([len(s) for s in scans], dtype=torch.int32)
+    Pb = torch.from_numpy(np.stack([P] * B))
+    pi, nv, d = project_scans(torch.from_numpy(pts).cuda(), n, Pb, shape, vel_depth)
+    return pi.cpu().numpy(), nv.cpu().numpy(), d.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,shape,vel_depth", [(20000, (375, 1242), False), (5000, (94, 311), False),
+                                                (3000, (375, 1242), True), (1, (10, 10), False)])
+def test_bit_exact_against_restatement(n, shape, vel_depth):
+    from depth_estimation_amd.lidar import synthetic_scan
+    from oracle.lidar import project_scan
+    P = _P()
+    if shape != (375, 1242):     # scale the camera to the smaller image: more collisions per pixel
+        P = np.diag([shape[1] / 1242.0, shape[0] / 375.0, 1.0]) @ P
+    scans = [synthetic_scan(n, seed=1), synthetic_scan(max(1, n // 2), seed=2)]
+    pi, nv, d = _run(scans, P, shape, vel_depth)
+    for b, s in enumerate(scans):
+        want_pts, want_d = project_scan(s, P, shape, vel_depth)
+        assert nv[b] == len(want_pts)
+        assert np.array_equal(pi[b, :nv[b]], want_pts)
+        assert np.array_equal(d[b], want_d)
+        assert not pi[b, nv[b]:].any()
+
+
+def test_duplicates_and_key_collisions():
+    """Many points per pixel, and the reference's key shared by (y, W-1) and (y+1, 0)."""
+    from oracle.lidar import project_scan, project_scan_loop
+    H, W = 6, 8
+    # identity-like projection: forward = depth, pixel = (left, up) / forward
+    P = np.array([[0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [1.0, 0.0, 0.0, 0.0]])
+    g = np.random.default_rng(0)
+    n = 400
+    z = g.uniform(1.0, 9.0, n)
+    x = g.integers(1, W + 1, n)      # rounds to x, minus one -> column x - 1
+    y = g.integers(1, H + 1, n)
+    # force the colliding pair to be present, first point of its group on either side
+    x[:4] = [W, 1, 1, W]
+    y[:4] = [2, 3, 5, 4]
+    pts = np.stack([z, x * z, y * z, np.ones(n)], 1).astype(np.float32)
+    pi, nv, d = _run([pts], P, (H, W))
+    want_pts, want_d = project_scan(pts, P, (H, W))
+    assert np.array_equal(pi[0, :nv[0]], want_pts)
+    assert np.array_equal(d[0], want_d)
+    assert np.array_equal(want_d, project_scan_loop(pts, P, (H, W)))   # literal Counter / np.where form
+
+
+def test_behind_camera_and_out_of_bounds_are_dropped():
+    from depth_estimation_amd.lidar import synthetic_scan
+    P = _P()
+    s = synthetic_scan(4000, seed=3)
+    s[:, 0] = -np.abs(s[:, 0])        # everything behind the sensor
+    pi, nv, d = _run([s], P, (375, 1242))
+    assert nv[0] == 0 and not d.any()
+
+
+def test_reproducible():
+    from depth_estimation_amd.lidar import synthetic_scan
+    P = _P()
+    s = synthetic_scan(30000, seed=4)
+    a = _run([s], P, (375, 1242))
+    b = _run([s], P, (375, 1242))
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+def test_generate_depth_map_from_files(tmp_path):
+    """The file-level entry point on a synthetic KITTI-shaped directory."""
+    from depth_estimation_amd.lidar import KITTI_LIKE_CALIB, generate_depth_map, synthetic_scan
+    from oracle.lidar import project_scan
+    c = KITTI_LIKE_CALIB
+    with open(tmp_path / "calib_cam_to_cam.txt", "w") as f:
+        f.write("calib_time: 09-Jan-2012 13:57:47\n")
+        for k, v in c["cam2cam"].items():
+            f.write(f"{k}: " + " ".join(f"{t:.6e}" for t in v) + "\n")
+    with open(tmp_path / "calib_velo_to_cam.txt", "w") as f:
+        f.write("calib_time: 15-Mar-2012 11:37:16\n")
+        for k, v in c["velo2cam"].items():
+            f.write(f"{k}: " + " ".join(f"{t:.6e}" for t in v) + "\n")
+    scan = synthetic_scan(8000, seed=5)
+    scan.tofile(tmp_path / "0000000000.bin")
+    sparse = generate_depth_map(str(tmp_path), str(tmp_path / "0000000000.bin"), interp=False)
+    _, want = project_scan(scan, _P(), (375, 1242))
+    assert sparse.shape == (375, 1242) and np.array_equal(sparse, want)
+    dense = generate_depth_map(str(tmp_path), str(tmp_path / "0000000000.bin"))
+    assert dense.shape == (375, 1242) and np.isfinite(dense).all() and (dense > 0).mean() > 0.2
