@@ -35,7 +35,10 @@ namespace dw {
 constexpr int QH_GRAD = 16;  // error-map rows per block, gradient kernel
 constexpr int QH_FWD = 16;   // same, forward-only kernel
 constexpr int QW = 32;       // error-map columns per block
-constexpr int SW = 2;        // pixels per thread strip (1 x SW); 2 or 4
+#ifndef DW_SW
+#define DW_SW 2
+#endif
+constexpr int SW = DW_SW;    // pixels per thread strip (1 x SW); 1, 2 or 4
 constexpr int WW = SW + 2;   // strip window columns
 constexpr int SPR = QW / SW; // strips per error-map row
 constexpr int BLOCKS_PER_CU = 2;  // what LDS and registers are budgeted for
@@ -43,6 +46,9 @@ constexpr int RW = QW + 2;   // region columns
 constexpr int RP = QW + 4;  // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
 constexpr int SM_NT = 256;
+#ifndef DW_XCD_SWIZZLE
+#define DW_XCD_SWIZZLE 1
+#endif
 
 template <bool GRAD>
 struct Geom {
@@ -74,6 +80,7 @@ struct ScaleLayout {
 struct PhotoParams {
   int B, H, W, S;
   int tilesX, tilesY;  // of the kernel being launched
+  int n_full;          // blocks [0, n_full) run every scale of one tile; the rest one scale each
   const float* disp[DW_MAX_SCALES];
   const float* color[3];
   const float* pyr[DW_MAX_SCALES];
@@ -85,7 +92,7 @@ struct PhotoParams {
   // workspace sections
   float* sum_part;   // [blk_off[S]]            partial sums of disp[s]
   float* tile_loss;  // [B][tiles][4]
-  float* tile_dP;    // [B][tiles][24]
+  float* tile_dP;    // [B][tiles][S][24]
   float* gd0;        // [B][H][W]               d loss / d disp[0], photometric part
   float* part;       // [part_off[S]]           per-tile up-sampling adjoint partials, s >= 1
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
@@ -179,7 +186,10 @@ __device__ __forceinline__ void project_sample(const float* __restrict__ src, lo
 template <typename T>
 __device__ __forceinline__ void loadw(const T* p, T* o) {
   static_assert(sizeof(T) == 4, "32-bit elements");
-  if (SW == 4) {
+  if (SW == 1) {
+#pragma unroll
+    for (int j = 0; j < WW; ++j) o[j] = p[j];
+  } else if (SW == 4) {
     const int4 a = *reinterpret_cast<const int4*>(p);
     const int2 b = *reinterpret_cast<const int2*>(p + 4);
     const int v[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
@@ -283,8 +293,30 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
 
   DW_STAMP_DECL
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
-  const int b = blockIdx.y;
+  // Block -> (sample, tile, scale range).  Consecutive block ids run on
+  // consecutive XCDs (8 of them, one L2 each): give every XCD a contiguous run
+  // of tiles so that neighbouring tiles share an L2.  The last tiles of the
+  // launch may be split into one block per scale (see the host side).
+  const int ntile = p.tilesX * p.tilesY;
+  int tslot_i, s_lo = 0, s_hi = p.S;
+  {
+    const int L = blockIdx.x;
+    if (L < p.n_full) {
+#if DW_XCD_SWIZZLE
+      const int x = L & 7, q = p.n_full >> 3, rem = p.n_full & 7;
+      tslot_i = x * q + min(x, rem) + (L >> 3);
+#else
+      tslot_i = L;
+#endif
+    } else {
+      const int k = L - p.n_full;
+      tslot_i = p.n_full + k / p.S;
+      s_lo = k - (k / p.S) * p.S;
+      s_hi = s_lo + 1;
+    }
+  }
+  const int b = tslot_i / ntile;
+  const int tile = tslot_i - b * ntile;
   const int tY = tile / p.tilesX, tX = tile - tY * p.tilesX;
   const int cy0 = tY * CH, cx0 = tX * CW;        // image coords of the core origin
   const int qy0 = cy0 - CO, qx0 = cx0 - CO;      // ... of Q(0,0)
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     }
     // depth from the up-sampled disparity of every scale, once per tile: the
     // per-scale stages then have no dependent global load in front of the taps
-    for (int s = 0; s < p.S; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
       const int hs = H >> s, ws = W >> s;
       const float du = upsampled_disp(p.disp[s] + (long)b * hs * ws, hs, ws, s, y, x,
                                       (float)hs / (float)H, (float)ws / (float)W);
@@ -442,10 +474,9 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   __syncthreads();  // un-warped sources no longer needed: stage A may overwrite them
   DW_STAMP(9)  // target statistics + identity errors
 
-  const long tslot = (long)b * p.tilesX * p.tilesY + tile;
-  float dP_total = 0.f;  // threads 0..23: one entry of the 2x3x4 projection gradient
+  const long tslot = tslot_i;
 
-  for (int s = 0; s < p.S; ++s) {
+  for (int s = s_lo; s < s_hi; ++s) {
     const int hs = H >> s, ws = W >> s;
     const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
     float loss_acc = 0.f;
@@ -568,7 +599,10 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           // region rows qr-1+1 .. qr+1+1, region columns SW*ql .. SW*ql+WW-1
           const unsigned char* vrow = &s_valid[(qr + r) * RP + SW * ql];
           unsigned w[2];
-          if (SW == 4) {
+          if (SW == 1) {
+            w[0] = (unsigned)vrow[0] | ((unsigned)vrow[1] << 8) | ((unsigned)vrow[2] << 16);
+            w[1] = 0;
+          } else if (SW == 4) {
             const uint2 w2 = *reinterpret_cast<const uint2*>(vrow);
             w[0] = w2.x;
             w[1] = w2.y;
@@ -685,16 +719,29 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         for (int q = 0; q < SW; ++q) gd[q] = gdepth[q] * (-kDispRange * depth[q] * depth[q]);
       }
       DW_STAMP(5)  // stage C
-      // pose partials of this scale: one value per wave and entry
+      // pose partials of this scale: one value per wave and entry.  The six DPP
+      // steps are issued entry by entry, so that no step waits on the previous one.
       {
         const int lane = tid & (kWave - 1), wid = tid / kWave;
+        float v[24];
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int k = 0; k < 24; ++k) v[k] = dP[k / 12][k % 12];
 #pragma unroll
-          for (int k = 0; k < 12; ++k) {
-            const float v = wave_sum(dP[f][k]);
-            if (lane == kSumLane) s_dPw[wid * 24 + f * 12 + k] = v;
-          }
+        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0xb1, 0xf>(v[k]);   // quad_perm:[1,0,3,2]
+#pragma unroll
+        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x4e, 0xf>(v[k]);   // quad_perm:[2,3,0,1]
+#pragma unroll
+        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x124, 0xf>(v[k]);  // row_ror:4
+#pragma unroll
+        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x128, 0xf>(v[k]);  // row_ror:8
+#pragma unroll
+        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x142, 0xa>(v[k]);  // row_bcast:15
+#pragma unroll
+        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);  // row_bcast:31 -> lane 63
+        if (lane == kSumLane) {
+#pragma unroll
+          for (int k = 0; k < 24; ++k) s_dPw[wid * 24 + k] = v[k];
+        }
       }
       if (s == 0) {
         if (row_core) {
@@ -745,14 +792,15 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     const float t = block_sum<NT>(loss_acc, s_red);
     if (tid == 0) p.tile_loss[tslot * DW_MAX_SCALES + s] = t;
     DW_STAMP(7)  // loss partial sum
-    if (GRAD && tid < 24) {
+    if (GRAD && tid < 24) {  // one entry of the 2x3x4 projection gradient of this tile and scale
+      float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < NT / kWave; ++w) dP_total += s_dPw[w * 24 + tid];
+      for (int w = 0; w < NT / kWave; ++w) v += s_dPw[w * 24 + tid];
+      p.tile_dP[(tslot * p.S + s) * 24 + tid] = v;
     }
   }
-  if (GRAD && tid < 24) p.tile_dP[tslot * 24 + tid] = dP_total;
 #ifdef DW_STAMPS
-  if (GRAD && (tid & 63) == 0 && tile == p.tilesX * (p.tilesY / 2) + p.tilesX / 2 && b == p.B / 2)
+  if (GRAD && (tid & 63) == 0 && tile == p.tilesX * (p.tilesY / 2) + p.tilesX / 2 && b == p.B / 2 && s_lo == 0)
     for (int k = 0; k < 10; ++k) p.gd0[(tid / 64) * 10 + k] = (float)t_acc[k];
 #endif
 }
@@ -860,44 +908,57 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
 }
 
 // ------------------------------------------------- scalar loss
-// One block of 1024 threads. Each of the 3*S sums (tile losses, smoothness x, y)
-// is accumulated in double by all threads (strided, several loads in flight),
-// reduced per wave with shuffles and across waves by one thread: fixed order.
+// One block of 1024 threads.  All 3*S sums (tile losses, smoothness x, y) are
+// accumulated in double in one pass over the partials (the S tile partials of a
+// tile are one 16-byte load), reduced per wave with shuffles and across waves
+// by one thread: fixed order.
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p, float* loss_out) {
   __shared__ double s_part[3 * DW_MAX_SCALES][1024 / kWave];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const int ntile = p.B * p.tilesX * p.tilesY;
-  for (int s = 0; s < p.S; ++s) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll 4
-    for (int t = tid; t < ntile; t += 1024) a0 += (double)p.tile_loss[(long)t * DW_MAX_SCALES + s];
-#pragma unroll 2
-    for (int k = p.L.blk_off[s] + tid; k < p.L.blk_off[s + 1]; k += 1024) {
-      a1 += (double)p.sm_part[(long)k * 3 + 0];
-      a2 += (double)p.sm_part[(long)k * 3 + 1];
-    }
+  double acc[3 * DW_MAX_SCALES];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a0 += __shfl_down(a0, off, kWave);
-      a1 += __shfl_down(a1, off, kWave);
-      a2 += __shfl_down(a2, off, kWave);
+  for (int k = 0; k < 3 * DW_MAX_SCALES; ++k) acc[k] = 0.0;
+  const float4* tl = reinterpret_cast<const float4*>(p.tile_loss);
+#pragma unroll 4
+  for (int t = tid; t < ntile; t += 1024) {
+    const float4 v = tl[t];
+    acc[0] += (double)v.x;
+    acc[3] += (double)v.y;
+    acc[6] += (double)v.z;
+    acc[9] += (double)v.w;
+  }
+#pragma unroll
+  for (int s = 0; s < DW_MAX_SCALES; ++s) {
+    if (s < p.S) {
+#pragma unroll 2
+      for (int k = p.L.blk_off[s] + tid; k < p.L.blk_off[s + 1]; k += 1024) {
+        acc[3 * s + 1] += (double)p.sm_part[(long)k * 3 + 0];
+        acc[3 * s + 2] += (double)p.sm_part[(long)k * 3 + 1];
+      }
     }
-    if (lane == 0) {
-      s_part[3 * s + 0][wid] = a0;
-      s_part[3 * s + 1][wid] = a1;
-      s_part[3 * s + 2][wid] = a2;
-    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3 * DW_MAX_SCALES; ++k) {
+    double a = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+    if (lane == 0) s_part[k][wid] = a;
+  }
+  __syncthreads();
+  if (tid < 3 * DW_MAX_SCALES) {  // thread k finishes sum k
+    double a = 0.0;
+    for (int w = 0; w < 1024 / kWave; ++w) a += s_part[tid][w];
+    s_part[tid][0] = a;
   }
   __syncthreads();
   if (tid == 0) {
     double total = 0.0;
     for (int s = 0; s < p.S; ++s) {
-      double sum[3] = {0.0, 0.0, 0.0};
-      for (int k = 0; k < 3; ++k)
-        for (int w = 0; w < 1024 / kWave; ++w) sum[k] += s_part[3 * s + k][w];
       const int hs = p.L.Hs[s], ws = p.L.Ws[s];
-      const double photo = sum[0] / ((double)p.B * p.H * p.W);
-      const double sm = sum[1] / ((double)p.B * hs * (ws - 1)) + sum[2] / ((double)p.B * (hs - 1) * ws);
+      const double photo = s_part[3 * s][0] / ((double)p.B * p.H * p.W);
+      const double sm = s_part[3 * s + 1][0] / ((double)p.B * hs * (ws - 1)) +
+                        s_part[3 * s + 2][0] / ((double)p.B * (hs - 1) * ws);
       loss_out[1 + s] = (float)photo;
       loss_out[1 + p.S + s] = (float)sm;
       total += photo + (double)kWSmooth * sm / (double)(1 << s);
@@ -982,22 +1043,24 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
 }
 
 // ------------------------------------------------- backward: d loss / d T
-__global__ __launch_bounds__(256) void grad_pose_kernel(const BwdParams p) {
-  __shared__ double s_part[10][24];
+constexpr int GP_NT = 1024, GP_GROUPS = GP_NT / 24;  // 42 groups of 24 threads (1008 in use)
+__global__ __launch_bounds__(GP_NT) void grad_pose_kernel(const BwdParams p) {
+  __shared__ double s_part[GP_GROUPS][24];
   __shared__ double s_dP[24];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int ntile = p.tilesX * p.tilesY;
-  if (tid < 240) {
+  const int nrow = p.tilesX * p.tilesY * p.S;  // one row of 24 partials per (tile, scale)
+  if (tid < GP_GROUPS * 24) {
     const int g = tid / 24, k = tid - g * 24;
     double a = 0.0;
-    const float* src = p.tile_dP + (long)b * ntile * 24 + k;
-    for (int t = g; t < ntile; t += 10) a += (double)src[(long)t * 24];
+    const float* src = p.tile_dP + (long)b * nrow * 24 + k;
+#pragma unroll 4
+    for (int t = g; t < nrow; t += GP_GROUPS) a += (double)src[(long)t * 24];
     s_part[g][k] = a;
   }
   __syncthreads();
   if (tid < 24) {
     double a = 0.0;
-    for (int g = 0; g < 10; ++g) a += s_part[g][tid];
+    for (int g = 0; g < GP_GROUPS; ++g) a += s_part[g][tid];
     s_dP[tid] = a;
   }
   __syncthreads();
@@ -1052,7 +1115,7 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   w.tile_loss = o;
   o = align_up(o + sizeof(float) * (size_t)d.B * tiles_max * DW_MAX_SCALES, A);
   w.tile_dP = o;
-  o = align_up(o + sizeof(float) * (size_t)d.B * tiles_g * 24, A);
+  o = align_up(o + sizeof(float) * (size_t)d.B * tiles_g * DW_MAX_SCALES * 24, A);
   w.sm_part = o;
   o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S] * 3, A);
   w.sm_G = o;
@@ -1067,12 +1130,39 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
 static int check_desc(const dw_desc* d) {
   if (!d) return DW_ERR_NULL;
   if (d->B < 1 || d->S < 1 || d->S > DW_MAX_SCALES || d->F != DW_NUM_SRC) return DW_ERR_SHAPE;
-  if (d->flags & ~DW_FLAG_TILE_KERNEL_ONLY) return DW_ERR_ARG;
+  if (d->flags & ~(DW_FLAG_TILE_KERNEL_ONLY | DW_FLAG_NO_TAIL_SPLIT)) return DW_ERR_ARG;
   const int m = 1 << (d->S - 1);
   if (d->H % m || d->W % m) return DW_ERR_SHAPE;
   if ((d->H >> (d->S - 1)) < 2 || (d->W >> (d->S - 1)) < 2) return DW_ERR_SHAPE;
   if ((long)d->H * d->W > (1l << 30) || d->B > 65535) return DW_ERR_SHAPE;
   return DW_OK;
+}
+
+// Resident-block capacity of the current device for the tile kernels.
+static int tile_slots() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cached[dev] = cus * BLOCKS_PER_CU;
+  }
+  return cached[dev];
+}
+
+// All tiles take the same time, so a launch runs in rounds of `slots` blocks
+// and the last round leaves most of the chip idle when it is short.  If the
+// tiles of that round, split into one block per scale, still fit into one
+// round, launch them that way: the tail then lasts one scale (plus the
+// scale-independent prologue) instead of S.  Every partial result is indexed
+// by (tile, scale), so the outputs do not depend on the split.
+static int full_blocks(int n_tiles, int S, int flags) {
+  if ((flags & DW_FLAG_NO_TAIL_SPLIT) || S < 2) return n_tiles;
+  const int slots = tile_slots();
+  if (slots <= 0) return n_tiles;
+  const int r = n_tiles % slots;
+  return ((long)r * S <= slots) ? n_tiles - r : n_tiles;
 }
 
 }  // namespace dw
@@ -1133,7 +1223,9 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
 
-  const dim3 tgrid(p.tilesX * p.tilesY, p.B);
+  const int n_tiles = p.tilesX * p.tilesY * p.B;
+  p.n_full = full_blocks(n_tiles, p.S, desc->flags);
+  const dim3 tgrid(p.n_full + (n_tiles - p.n_full) * p.S);
   if (desc->flags & DW_FLAG_TILE_KERNEL_ONLY) {
     if (with_grad)
       photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
@@ -1188,6 +1280,6 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   p.grad_T = grad_T;
   hipStream_t st = (hipStream_t)stream;
   grad_disp_kernel<<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
-  if (grad_T) grad_pose_kernel<<<p.B, 256, 0, st>>>(p);
+  if (grad_T) grad_pose_kernel<<<p.B, GP_NT, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }

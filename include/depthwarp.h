@@ -65,6 +65,9 @@ typedef struct dw_desc {
  * per-tile warp/error/adjoint kernel); outputs other than the masks are then
  * not produced. Used to time that kernel alone with events. */
 #define DW_FLAG_TILE_KERNEL_ONLY 1
+/* Testing only: never split the last tiles of the launch into per-scale blocks
+ * (the split is a scheduling choice; results are identical with and without). */
+#define DW_FLAG_NO_TAIL_SPLIT 2
 
 DW_API int dw_version(void);
 DW_API const char* dw_strerror(int code);

@@ -142,3 +142,24 @@ def test_high_resolution_properties():
     per = torch.stack(per)
     # photometric terms are plain means over the batch; the smoothness mean too
     assert torch.allclose(per[:, 1:].mean(0), t_all[1:], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 48, 160), (12, 192, 640), (5, 192, 640)])
+def test_tail_split_does_not_change_results(B, H, W):
+    """The last tiles of a launch may run as one block per scale (a scheduling
+    choice made from the tile count and the CU count); every partial result is
+    indexed by (tile, scale), so all outputs must be bitwise those of the
+    unsplit launch (flag 2).  The small shape is split entirely, the B = 12 one
+    partly, the B = 5 one not at all."""
+    from depth_estimation_amd.ops import PhotometricPlan
+    seq = make_sequence(B, H, W, seed=3).to("cuda")
+    res = []
+    for flags in (0, 2):
+        plan = PhotometricPlan(B, H, W, 4, "cuda", flags=flags).bind(*seq.args())
+        plan.forward(True)
+        plan.backward()
+        torch.cuda.synchronize()
+        res.append((plan.loss.clone(), plan.mask.clone(), [g.clone() for g in plan.grad_disp], plan.grad_T.clone()))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))

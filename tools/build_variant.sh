@@ -5,5 +5,4 @@ cd "$(dirname "$0")/.."
 mkdir -p variants
 N=$1; shift
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fvisibility=hidden -DDW_BUILD "$@" \
-  -Iinclude -Idepth_estimation_amd/csrc depth_estimation_amd/csrc/photometric.hip depth_estimation_amd/csrc/compute_loss.hip \
-  depth_estimation_amd/csrc/abi.hip depth_estimation_amd/csrc/modules.hip depth_estimation_amd/csrc/soft_argmin.hip -o variants/$N.so
+  -Iinclude -Idepth_estimation_amd/csrc depth_estimation_amd/csrc/*.hip -o variants/$N.so
