@@ -32,7 +32,13 @@
 
 namespace dw {
 
-constexpr int QH_GRAD = 16;  // error-map rows per block, gradient kernel
+#ifndef DW_QH_GRAD
+#define DW_QH_GRAD 16
+#endif
+#ifndef DW_BLOCKS_PER_CU
+#define DW_BLOCKS_PER_CU 2
+#endif
+constexpr int QH_GRAD = DW_QH_GRAD;  // error-map rows per block, gradient kernel
 constexpr int QH_FWD = 16;   // same, forward-only kernel
 constexpr int QW = 32;       // error-map columns per block
 #ifndef DW_SW
@@ -41,7 +47,7 @@ constexpr int QW = 32;       // error-map columns per block
 constexpr int SW = DW_SW;    // pixels per thread strip (1 x SW); 1, 2 or 4
 constexpr int WW = SW + 2;   // strip window columns
 constexpr int SPR = QW / SW; // strips per error-map row
-constexpr int BLOCKS_PER_CU = 2;  // what LDS and registers are budgeted for
+constexpr int BLOCKS_PER_CU = DW_BLOCKS_PER_CU;  // what LDS and registers are budgeted for
 constexpr int RW = QW + 2;   // region columns
 constexpr int RP = QW + 4;  // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
@@ -135,12 +141,23 @@ struct Sample {
   float dx[3], dy[3];  // d val[c] / d (sample x, y) in pixels, before the border mask
 };
 
-// Project the camera-space point (X,Y,Z) with P (3x4, row-major) and sample
-// the three colour planes of `src` bilinearly (border padding, corners aligned).
-template <bool WITH_GRAD>
-__device__ __forceinline__ void project_sample(const float* __restrict__ src, long plane, int H,
-                                               int W, const float* P, float X, float Y, float Z,
-                                               Sample& o) {
+// The three steps of warping one pixel into one source frame, separated so that
+// the caller can put other work between issuing the loads and using them:
+// where to sample, the twelve taps, the blend.
+struct SampleAddr {
+  unsigned o_nw, o_ne, o_sw, o_se;  // byte offsets of the four taps inside a colour plane
+  float tx, ty;                     // fractional position inside the cell
+  bool valid, inx, iny;
+  float u, v, zp;
+};
+struct SampleTaps {
+  float nw[3], ne[3], sw[3], se[3];
+};
+
+// Project the camera-space point (X,Y,Z) with P (3x4, row-major); border
+// padding, corners aligned.
+__device__ __forceinline__ void sample_addr(int H, int W, const float* P, float X, float Y, float Z,
+                                            SampleAddr& a) {
   const float c0 = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3];
   const float c1 = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7];
   const float c2 = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11];
@@ -150,36 +167,60 @@ __device__ __forceinline__ void project_sample(const float* __restrict__ src, lo
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   const float gx = (u / wm1 - 0.5f) * 2.0f;
   const float gy = (v / hm1 - 0.5f) * 2.0f;
-  o.valid = (gx >= -1.f) && (gx <= 1.f) && (gy >= -1.f) && (gy <= 1.f) && (c2 > 0.f);
+  a.valid = (gx >= -1.f) && (gx <= 1.f) && (gy >= -1.f) && (gy <= 1.f) && (c2 > 0.f);
   float ix = ((gx + 1.0f) * 0.5f) * wm1;
   float iy = ((gy + 1.0f) * 0.5f) * hm1;
-  o.inx = (ix > 0.f) && (ix < wm1);
-  o.iny = (iy > 0.f) && (iy < hm1);
+  a.inx = (ix > 0.f) && (ix < wm1);
+  a.iny = (iy > 0.f) && (iy < hm1);
   ix = fminf(fmaxf(ix, 0.f), wm1);
   iy = fminf(fmaxf(iy, 0.f), hm1);
   const float ix0 = floorf(ix), iy0 = floorf(iy);
-  const float tx = ix - ix0, ty = iy - iy0;
-  const float ex = 1.0f - tx, ey = 1.0f - ty;
+  a.tx = ix - ix0;
+  a.ty = iy - iy0;
   const int x0 = (int)ix0, y0 = (int)iy0;
   const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-  const float w_nw = ex * ey, w_ne = tx * ey, w_sw = ex * ty, w_se = tx * ty;
-  const unsigned o_nw = (unsigned)(y0 * W + x0) * 4u, o_ne = (unsigned)(y0 * W + x1) * 4u;
-  const unsigned o_sw = (unsigned)(y1 * W + x0) * 4u, o_se = (unsigned)(y1 * W + x1) * 4u;
-  // uniform plane base + 32-bit per-lane offset: scalar-base addressing, no
-  // 64-bit address arithmetic per tap
+  a.o_nw = (unsigned)(y0 * W + x0) * 4u;
+  a.o_ne = (unsigned)(y0 * W + x1) * 4u;
+  a.o_sw = (unsigned)(y1 * W + x0) * 4u;
+  a.o_se = (unsigned)(y1 * W + x1) * 4u;
+  a.u = u;
+  a.v = v;
+  a.zp = zp;
+}
+
+// uniform plane base + 32-bit per-lane offset: no 64-bit address arithmetic per tap
+__device__ __forceinline__ void sample_gather(const float* __restrict__ src, long plane,
+                                              const SampleAddr& a, SampleTaps& t) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* p = src + c * plane;
-    const float nw = tap(p, o_nw), ne = tap(p, o_ne), sw = tap(p, o_sw), se = tap(p, o_se);
+    t.nw[c] = tap(p, a.o_nw);
+    t.ne[c] = tap(p, a.o_ne);
+    t.sw[c] = tap(p, a.o_sw);
+    t.se[c] = tap(p, a.o_se);
+  }
+}
+
+template <bool WITH_GRAD>
+__device__ __forceinline__ void sample_blend(const SampleAddr& a, const SampleTaps& t, Sample& o) {
+  const float tx = a.tx, ty = a.ty;
+  const float ex = 1.0f - tx, ey = 1.0f - ty;
+  const float w_nw = ex * ey, w_ne = tx * ey, w_sw = ex * ty, w_se = tx * ty;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float nw = t.nw[c], ne = t.ne[c], sw = t.sw[c], se = t.se[c];
     o.val[c] = ((nw * w_nw + ne * w_ne) + sw * w_sw) + se * w_se;
     if (WITH_GRAD) {
       o.dx[c] = fmaf(se - sw, ty, (ne - nw) * ey);
       o.dy[c] = fmaf(se - ne, tx, (sw - nw) * ex);
     }
   }
-  o.u = u;
-  o.v = v;
-  o.zp = zp;
+  o.valid = a.valid;
+  o.inx = a.inx;
+  o.iny = a.iny;
+  o.u = a.u;
+  o.v = a.v;
+  o.zp = a.zp;
 }
 
 // The WW consecutive 32-bit words of one window row in LDS (start aligned to SW words).
@@ -400,45 +441,52 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   // LDS. E[f][q]; with gradients also the SSIM adjoint coefficients Gc[f][q][9].
   auto strip_errors = [&](float E[2][SW], float Gc[2][SW][9], bool want_g) __attribute__((always_inline)) {
     float ss[2][SW], l1[2][SW];  // channel sums, accumulated in channel order
+    // Six (channel, frame) bodies in sequence.  The window of the next body is
+    // read from LDS at the start of the current one (ping-pong registers), so
+    // its latency is covered by the arithmetic.
+    float xw[2][3][WW], y[3][WW];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float y[3][WW];
+    for (int r = 0; r < 3; ++r) loadw(&s_un[win + r * RP], xw[0][r]);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) loadw(&s_tgt[c * RN + win + r * RP], y[r]);
+    for (int idx = 0; idx < 6; ++idx) {
+      const int c = idx >> 1, f = idx & 1;
+      if (f == 0) {
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        float x[3][WW], cs[WW], cxx[WW], cxy[WW];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) loadw(&s_un[(f * 3 + c) * RN + win + r * RP], x[r]);
-        colsum3(x, cs);
-        colsum3_prod(x, x, cxx);
-        colsum3_prod(x, y, cxy);
-#pragma unroll
-        for (int q = 0; q < SW; ++q) {
-          const float mux = rowsum3(cs, q), exx = rowsum3(cxx, q), exy = rowsum3(cxy, q);
-          SsimTerms t;
-          const float sv = ssim_loss_px(mux, muy[c][q], exx, eyy[c][q], exy, t);
-          const float lv = fabsf(x[1][q + 1] - y[1][q + 1]);
-          ss[f][q] = (c == 0) ? sv : ss[f][q] + sv;
-          l1[f][q] = (c == 0) ? lv : l1[f][q] + lv;
-          if (GRAD && want_g) {
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-            if (t.raw >= 0.f && t.raw <= 1.f) {
-              // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2, 1/d
-              const float up = (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2);
-              g0 = up * (2.0f * muy[c][q] * (t.A2 - t.A1) - t.r * 2.0f * mux * (t.B2 - t.B1));
-              g1 = up * (-t.r * t.B1);
-              g2 = up * (2.0f * t.A1);
-            }
-            Gc[f][q][3 * c + 0] = g0;
-            Gc[f][q][3 * c + 1] = g1;
-            Gc[f][q][3 * c + 2] = g2;
-          }
-        }
-        // keep the scheduler from interleaving the six (channel, frame) bodies:
-        // that would hold every window of the strip in registers at once
-        __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 3; ++r) loadw(&s_tgt[c * RN + win + r * RP], y[r]);
       }
+      if (idx + 1 < 6) {
+        const int cn = (idx + 1) >> 1, fn = (idx + 1) & 1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) loadw(&s_un[(fn * 3 + cn) * RN + win + r * RP], xw[(idx + 1) & 1][r]);
+      }
+      const float (*x)[WW] = xw[idx & 1];
+      float cs[WW], cxx[WW], cxy[WW];
+      colsum3(x, cs);
+      colsum3_prod(x, x, cxx);
+      colsum3_prod(x, y, cxy);
+#pragma unroll
+      for (int q = 0; q < SW; ++q) {
+        const float mux = rowsum3(cs, q), exx = rowsum3(cxx, q), exy = rowsum3(cxy, q);
+        SsimTerms t;
+        const float sv = ssim_loss_px(mux, muy[c][q], exx, eyy[c][q], exy, t);
+        const float lv = fabsf(x[1][q + 1] - y[1][q + 1]);
+        ss[f][q] = (c == 0) ? sv : ss[f][q] + sv;
+        l1[f][q] = (c == 0) ? lv : l1[f][q] + lv;
+        if (GRAD && want_g) {
+          // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2, 1/d; zero where the clamp is active
+          const bool open = (t.raw >= 0.f) && (t.raw <= 1.f);
+          const float up = (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2);
+          const float g0 = up * (2.0f * muy[c][q] * (t.A2 - t.A1) - t.r * 2.0f * mux * (t.B2 - t.B1));
+          const float g1 = up * (-t.r * t.B1);
+          const float g2 = up * (2.0f * t.A1);
+          Gc[f][q][3 * c + 0] = open ? g0 : 0.f;
+          Gc[f][q][3 * c + 1] = open ? g1 : 0.f;
+          Gc[f][q][3 * c + 2] = open ? g2 : 0.f;
+        }
+      }
+      // keep the scheduler from interleaving the bodies: that would hold every
+      // window of the strip in registers at once
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -496,10 +544,20 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
       const float Y = depth * ((iK[3] * fx + iK[4] * fy) + iK[5]);
       const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
       unsigned char vb = 0;
+      // both frames' taps are in flight before the first blend: frame 1 is
+      // projected while the loads of frame 0 travel
+      SampleAddr ad[2];
+      SampleTaps tp[2];
+      sample_addr(H, W, P0, X, Y, Z, ad[0]);
+      sample_gather(src_b[0], plane, ad[0], tp[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      sample_addr(H, W, P1, X, Y, Z, ad[1]);
+      sample_gather(src_b[1], plane, ad[1], tp[1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         Sample sm;
-        project_sample<GRAD>(src_b[f], plane, H, W, f ? P1 : P0, X, Y, Z, sm);
+        sample_blend<GRAD>(ad[f], tp[f], sm);
         s_un[(f * 3 + 0) * RN + li] = sm.val[0];
         s_un[(f * 3 + 1) * RN + li] = sm.val[1];
         s_un[(f * 3 + 2) * RN + li] = sm.val[2];
