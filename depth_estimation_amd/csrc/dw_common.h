@@ -57,6 +57,25 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// Buffer addressing: a 128-bit resource (base, size in bytes) in scalar
+// registers, a wave-uniform byte offset in a scalar register and one 32-bit
+// per-lane byte offset; no 64-bit per-load address arithmetic in vector
+// registers.  The range of a resource is 4 GB.
+using buf_rsrc = __amdgpu_buffer_rsrc_t;
+// `base` and `bytes` must be the same in every lane; they are moved to scalar
+// registers explicitly (a resource the compiler believes to be per-lane costs a
+// serialising loop around every load).
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long v = (unsigned long long)base;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  void* u = (void*)(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(u, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(buf_rsrc r, unsigned lane_off, unsigned uniform_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, uniform_off, 0));
+}
+
 __device__ __forceinline__ int reflect_index(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * (n - 1) - i;

@@ -54,11 +54,7 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // registers, which is what lets a lane keep its whole column set in registers.
 typedef unsigned sa_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned sa_u4 __attribute__((ext_vector_type(4)));
-using sa_rsrc = __amdgpu_buffer_rsrc_t;
-
-__device__ __forceinline__ sa_rsrc make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
+using sa_rsrc = buf_rsrc;
 
 // The builtins return generic integer vectors; they are converted as a whole to
 // float vectors before any element is taken (element access on the integer
