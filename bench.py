@@ -78,10 +78,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a one-GPU box only: DW_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and uses gloo for the barrier (RCCL refuses two ranks per device).
+    rehearsal = os.environ.get("DW_BENCH_REHEARSAL") == "1"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -121,9 +129,10 @@ def main():
         run()
 
     def sync():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     sync()
     t0 = time.perf_counter()
@@ -132,7 +141,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(plan.loss[0].item())
@@ -154,7 +163,7 @@ def main():
         "loss": loss_val,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:
         # Dominant kernel alone (the per-tile fused kernel), HIP events on the
         # stream it is launched on.
         from depth_estimation_amd._lib import DwDesc
@@ -181,7 +190,7 @@ def main():
                            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                            "kernel_ms": k_ms, "algorithmic_bytes": alg["total"]}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
 
     if rank == 0:
