@@ -922,7 +922,8 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
   for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
     const long i = (long)chunk * SM_PX + k;
     if (i >= n) break;
-    const int y = (int)(i / ws), x = (int)(i - (long)y * ws);
+    // 32-bit index arithmetic (n < 2^30): a 64-bit division costs more than the rest of the pixel
+    const int y = (int)((unsigned)i / (unsigned)ws), x = (int)((unsigned)i - (unsigned)y * (unsigned)ws);
     const float dc = d[i] * inv;
     const float c0 = I[i], c1 = I[n + i], c2 = I[2 * n + i];
     float G = 0.f;
@@ -1075,7 +1076,8 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
   for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
     const long i = (long)chunk * SM_PX + k;
     if (i >= n) break;
-    const int y = (int)(i / ws), x = (int)(i - (long)y * ws);
+    // 32-bit index arithmetic (n < 2^30): a 64-bit division costs more than the rest of the pixel
+    const int y = (int)((unsigned)i / (unsigned)ws), x = (int)((unsigned)i - (unsigned)y * (unsigned)ws);
     float ph = 0.f;
     if (s == 0) {
       ph = p.gd0[(long)b * plane + i];
