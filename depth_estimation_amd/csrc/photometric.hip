@@ -330,7 +330,8 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   __shared__ float s_P[2][12];
   __shared__ float s_invK[9];
   __shared__ float s_red[NT / kWave];
-  __shared__ float s_dPw[GRAD ? (NT / kWave) * 24 : 1];  // per-wave pose partials of one scale
+  // per-wave partial sums of one scale: 24 pose entries and the loss
+  __shared__ float s_dPw[GRAD ? (NT / kWave) * 25 : 1];
 
   DW_STAMP_DECL
   const int tid = threadIdx.x;
@@ -382,24 +383,84 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   // ---- colour regions (reflect-mapped): target and the two un-warped sources
   const float* tgt_b = p.color[0] + (long)b * 3 * plane;
   const float* src_b[2] = {p.color[1] + (long)b * 3 * plane, p.color[2] + (long)b * 3 * plane};
-  for (int i = tid; i < RH * RW; i += NT) {
-    const int ry = i / RW, rx = i - ry * RW;
-    const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
-    const long o = (long)y * W + x;
-    const int li = ry * RP + rx;
+  // Every global load of the prologue is issued before the first one is used
+  // (nothing else is live yet, so registers are plentiful): all region pixels
+  // of the thread, nine colour values and the four disparity taps of every
+  // scale each.  Loads are unconditional -- a thread past the end of the region
+  // re-reads pixel 0 and a scale this block does not process re-reads one it
+  // does -- and only the LDS stores are predicated.
+  {
+    constexpr int NIT = (RH * RW + NT - 1) / NT;
+    float col[NIT][9];
+    float tapv[NIT][DW_MAX_SCALES][4];
+    float wy0[NIT][DW_MAX_SCALES], wy1[NIT][DW_MAX_SCALES], wx0[NIT][DW_MAX_SCALES], wx1[NIT][DW_MAX_SCALES];
+    int lis[NIT];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      s_tgt[c * RN + li] = tgt_b[c * plane + o];
-      s_un[(0 * 3 + c) * RN + li] = src_b[0][c * plane + o];
-      s_un[(1 * 3 + c) * RN + li] = src_b[1][c * plane + o];
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * NT;
+      const bool act = i < RH * RW;
+      i = act ? i : 0;
+      const int ry = i / RW, rx = i - ry * RW;
+      const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
+      const long o = (long)y * W + x;
+      lis[it] = act ? ry * RP + rx : -1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        col[it][c] = tgt_b[c * plane + o];
+        col[it][3 + c] = src_b[0][c * plane + o];
+        col[it][6 + c] = src_b[1][c * plane + o];
+      }
+#pragma unroll
+      for (int s = 0; s < DW_MAX_SCALES; ++s) {
+        const int sc = (s >= s_lo && s < s_hi) ? s : s_lo;
+        const int hs = H >> sc, ws = W >> sc;
+        const float* d = p.disp[sc] + (long)b * hs * ws;
+        if (sc == 0) {  // uniform: scale 0 is not up-sampled
+          const float v = d[o];
+          tapv[it][s][0] = tapv[it][s][1] = tapv[it][s][2] = tapv[it][s][3] = v;
+          wy0[it][s] = wx0[it][s] = 1.f;
+          wy1[it][s] = wx1[it][s] = 0.f;
+        } else {
+          const Taps ty = upsample_taps(y, hs, (float)hs / (float)H);
+          const Taps tx = upsample_taps(x, ws, (float)ws / (float)W);
+          tapv[it][s][0] = d[(long)ty.i0 * ws + tx.i0];
+          tapv[it][s][1] = d[(long)ty.i0 * ws + tx.i1];
+          tapv[it][s][2] = d[(long)ty.i1 * ws + tx.i0];
+          tapv[it][s][3] = d[(long)ty.i1 * ws + tx.i1];
+          wy0[it][s] = ty.l0;
+          wy1[it][s] = ty.l1;
+          wx0[it][s] = tx.l0;
+          wx1[it][s] = tx.l1;
+        }
+      }
     }
-    // depth from the up-sampled disparity of every scale, once per tile: the
-    // per-scale stages then have no dependent global load in front of the taps
-    for (int s = s_lo; s < s_hi; ++s) {
-      const int hs = H >> s, ws = W >> s;
-      const float du = upsampled_disp(p.disp[s] + (long)b * hs * ws, hs, ws, s, y, x,
-                                      (float)hs / (float)H, (float)ws / (float)W);
-      s_depth[s * RN + li] = 1.0f / (kMinDisp + kDispRange * du);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int li = lis[it];
+      if (li >= 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          s_tgt[c * RN + li] = col[it][c];
+          s_un[(0 * 3 + c) * RN + li] = col[it][3 + c];
+          s_un[(1 * 3 + c) * RN + li] = col[it][6 + c];
+        }
+      }
+      // depth from the up-sampled disparity of every scale, once per tile: the
+      // per-scale stages then have no dependent global load in front of the taps
+#pragma unroll
+      for (int s = 0; s < DW_MAX_SCALES; ++s) {
+        if (s >= s_lo && s < s_hi && li >= 0) {
+          float du;
+          if (s == 0) {
+            du = tapv[it][s][0];
+          } else {
+            const float top = wx0[it][s] * tapv[it][s][0] + wx1[it][s] * tapv[it][s][1];
+            const float bot = wx0[it][s] * tapv[it][s][2] + wx1[it][s] * tapv[it][s][3];
+            du = wy0[it][s] * top + wy1[it][s] * bot;
+          }
+          s_depth[s * RN + li] = 1.0f / (kMinDisp + kDispRange * du);
+        }
+      }
     }
   }
   __syncthreads();
@@ -777,30 +838,44 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         for (int q = 0; q < SW; ++q) gd[q] = gdepth[q] * (-kDispRange * depth[q] * depth[q]);
       }
       DW_STAMP(5)  // stage C
-      // pose partials of this scale: one value per wave and entry.  The six DPP
-      // steps are issued entry by entry, so that no step waits on the previous one.
+      // pose partials and the loss of this scale: one value per wave and entry.
+      // The six DPP steps are issued entry by entry, so that no step waits on
+      // the previous one.
       {
         const int lane = tid & (kWave - 1), wid = tid / kWave;
-        float v[24];
+        float v[25];
 #pragma unroll
         for (int k = 0; k < 24; ++k) v[k] = dP[k / 12][k % 12];
+        v[24] = loss_acc;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0xb1, 0xf>(v[k]);   // quad_perm:[1,0,3,2]
+        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0xb1, 0xf>(v[k]);   // quad_perm:[1,0,3,2]
 #pragma unroll
-        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x4e, 0xf>(v[k]);   // quad_perm:[2,3,0,1]
+        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x4e, 0xf>(v[k]);   // quad_perm:[2,3,0,1]
 #pragma unroll
-        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x124, 0xf>(v[k]);  // row_ror:4
+        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x124, 0xf>(v[k]);  // row_ror:4
 #pragma unroll
-        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x128, 0xf>(v[k]);  // row_ror:8
+        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x128, 0xf>(v[k]);  // row_ror:8
 #pragma unroll
-        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x142, 0xa>(v[k]);  // row_bcast:15
+        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x142, 0xa>(v[k]);  // row_bcast:15
 #pragma unroll
-        for (int k = 0; k < 24; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);  // row_bcast:31 -> lane 63
+        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);  // row_bcast:31 -> lane 63
         if (lane == kSumLane) {
 #pragma unroll
-          for (int k = 0; k < 24; ++k) s_dPw[wid * 24 + k] = v[k];
+          for (int k = 0; k < 25; ++k) s_dPw[wid * 25 + k] = v[k];
         }
       }
+      // after the next barrier: per-tile sums over the waves, fixed order
+      auto finish_sums = [&]() __attribute__((always_inline)) {
+        if (tid < 25) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < NT / kWave; ++w) v += s_dPw[w * 25 + tid];
+          if (tid < 24)
+            p.tile_dP[(tslot * p.S + s) * 24 + tid] = v;  // one entry of the 2x3x4 projection gradient
+          else
+            p.tile_loss[tslot * DW_MAX_SCALES + s] = v;
+        }
+      };
       if (s == 0) {
         if (row_core) {
 #pragma unroll
@@ -810,12 +885,15 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
               p.gd0[(long)b * plane + (long)sy_img * W + x] = gd[q];
           }
         }
+        __syncthreads();  // also separates this scale's LDS traffic from the next stage A
+        finish_sums();
       } else {
         // ---- stage D: adjoint of the bilinear up-sampling, restricted to this
         // tile's core; rows first, then columns (both from LDS)
         #pragma unroll
         for (int q = 0; q < SW; ++q) s_gd[qr * QW + SW * ql + q] = gd[q];
         __syncthreads();
+        finish_sums();
         const int Y1 = min(cy0 + CH, H) - 1, X1 = min(cx0 + CW, W) - 1;
         const int k2 = 1 << s;
         const int ilo = upsample_taps(cy0, hs, sy).i0, ihi = upsample_taps(Y1, hs, sy).i1;
@@ -844,18 +922,14 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         }
       }
     }
-    // per-tile partial sum (fixed order: reproducible run to run); its barriers
-    // also separate this scale's LDS traffic from the next stage A
     DW_STAMP(6)  // pose partials + stage D
-    const float t = block_sum<NT>(loss_acc, s_red);
-    if (tid == 0) p.tile_loss[tslot * DW_MAX_SCALES + s] = t;
-    DW_STAMP(7)  // loss partial sum
-    if (GRAD && tid < 24) {  // one entry of the 2x3x4 projection gradient of this tile and scale
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NT / kWave; ++w) v += s_dPw[w * 24 + tid];
-      p.tile_dP[(tslot * p.S + s) * 24 + tid] = v;
+    if (!GRAD) {
+      // per-tile partial sum (fixed order: reproducible run to run); its barriers
+      // also separate this scale's LDS traffic from the next stage A
+      const float t = block_sum<NT>(loss_acc, s_red);
+      if (tid == 0) p.tile_loss[tslot * DW_MAX_SCALES + s] = t;
     }
+    DW_STAMP(7)  // loss partial sum
   }
 #ifdef DW_STAMPS
   if (GRAD && (tid & 63) == 0 && tile == p.tilesX * (p.tilesY / 2) + p.tilesX / 2 && b == p.B / 2 && s_lo == 0)
