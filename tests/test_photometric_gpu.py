@@ -163,3 +163,54 @@ def test_tail_split_does_not_change_results(B, H, W):
     a, b = res
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+
+
+def _check_against_oracle(seq):
+    loss, aux, masks, gd, gT = _oracle(seq)
+    terms, mask, hgd, hgT = _hip(seq)
+    S = len(seq.disp)
+    assert torch.equal(mask, masks), f"mask mismatch at {int((mask != masks).sum())} pixels"
+    assert abs(float(terms[0]) - float(loss)) <= LOSS_RTOL * abs(float(loss))
+    for s in range(S):
+        assert _rel(hgd[s], gd[s]) <= GRAD_RTOL, f"grad disp[{s}] rel err {_rel(hgd[s], gd[s])}"
+    if float(gT.abs().max()) > 0:
+        assert _rel(hgT[:, :, :3], gT[:, :, :3]) <= GRAD_RTOL
+    return masks
+
+
+@pytest.mark.parametrize("S", [1, 2, 3])
+def test_parity_fewer_scales(S):
+    _check_against_oracle(make_sequence(2, 32, 96, S=S, seed=40 + S))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 16, 16), (1, 40, 104), (2, 56, 72), (1, 8, 248)])
+def test_parity_sizes_off_the_tile_grid(B, H, W):
+    """Images smaller than one tile, not a multiple of the 14 x 30 tile step, and a single tile row."""
+    S = 4 if H >= 16 else 3
+    _check_against_oracle(make_sequence(B, H, W, S=S, seed=H + W))
+
+
+def test_parity_extreme_poses():
+    """Poses that throw most samples outside the source image or behind its camera: validity bits,
+    border clamping and the zero gradient outside the image are what is compared here."""
+    seq = make_sequence(3, 32, 96, seed=77)
+    T = seq.T.clone()
+    T[0, 0, 2, 3] -= 30.0          # camera far in front of the scene: points end up behind it
+    T[0, 1, 0, 3] += 25.0          # large sideways shift: samples leave the image on one side
+    T[1, 0, 1, 3] -= 40.0
+    c, s_ = 0.8660254, 0.5         # 30 degrees about the vertical axis
+    T[2, 1, :3, :3] = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]]) @ T[2, 1, :3, :3]
+    seq.T = T
+    masks = _check_against_oracle(seq)
+    valid = (masks >> 2) & 3
+    assert int((valid == 0).sum()) > 0 and int((valid == 3).sum()) > 0
+
+
+def test_parity_flat_inputs():
+    """Constant disparity and identical frames: every photometric error ties at zero, the arg-min
+    must fall on the first candidate everywhere and the smoothness term vanishes."""
+    seq = make_sequence(1, 32, 64, seed=5)
+    seq.disp = [torch.full_like(d, 0.25) for d in seq.disp]
+    seq.color = [seq.color[0].clone() for _ in range(3)]
+    masks = _check_against_oracle(seq)
+    assert int((masks & 3).max()) == 0
