@@ -180,16 +180,22 @@ def main():
         torch.cuda.synchronize()
         k_ms = e0.elapsed_time(e1) / reps
         achieved = alg["total"] / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_frac = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and (B, H, W) == (12, 192, 640):
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot run
-            # the profiler on itself); see the file for how they were collected and corrected
-            traffic = json.load(open(tpath))["bytes_corrected"]
+            # HBM bytes and vector instructions per launch from the committed rocprofv3 PMC passes
+            # (bench.py cannot run the profiler on itself); see the file for how they were
+            # collected and corrected
+            pmc = json.load(open(tpath))
+            traffic = pmc["bytes_corrected"]
+            if "SQ_INSTS_VALU" in pmc:
+                # share of the vector-issue peak: 1024 SIMDs, 2 cycles per wave instruction, 2.4 GHz
+                valu_frac = pmc["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9 * k_ms * 1e-3)
         out["roofline"] = {"bound": "hbm", "kernel": "photo_tile_kernel<true>",
                            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                           "kernel_ms": k_ms, "algorithmic_bytes": alg["total"]}
+                           "kernel_ms": k_ms, "algorithmic_bytes": alg["total"],
+                           "valu_issue_frac": valu_frac}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
 
