@@ -87,6 +87,7 @@ struct PhotoParams {
   int B, H, W, S;
   int tilesX, tilesY;  // of the kernel being launched
   int n_full;          // blocks [0, n_full) run every scale of one tile; the rest one scale each
+  int vec4;            // every scale's width is a multiple of 4 and every map pointer 16-byte aligned
   const float* disp[DW_MAX_SCALES];
   const float* color[3];
   const float* pyr[DW_MAX_SCALES];
@@ -993,6 +994,66 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
   const float icx = 1.0f / ((float)p.B * hs * (ws - 1));
   const float icy = 1.0f / ((float)p.B * (hs - 1) * ws);
   float lx = 0.f, ly = 0.f, gd = 0.f;
+  auto sgn = [](float a) -> float { return (a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f); };
+  if (p.vec4) {
+    // Rows are whole float4s: a thread takes four consecutive pixels of one
+    // row, reads them and their upper / lower neighbours as 16-byte vectors (a
+    // missing neighbour row re-reads the centre row and is masked) and the two
+    // pixels beside the group as scalars.  Same per-pixel arithmetic as below.
+    const long i0 = (long)chunk * SM_PX + 4 * threadIdx.x;
+    if (i0 < n) {
+      const int y = (int)((unsigned)i0 / (unsigned)ws), x0 = (int)((unsigned)i0 - (unsigned)y * (unsigned)ws);
+      const bool up = y > 0, dn = y + 1 < hs, lf = x0 > 0, rt = x0 + 4 < ws;
+      const long iu = up ? i0 - ws : i0, id = dn ? i0 + ws : i0;
+      float C[4][6], U[4][4], D[4][4];  // [plane: disp, I0, I1, I2][column]; C holds x0-1 .. x0+4
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) {
+        const float* src = (pl == 0) ? d : I + (long)(pl - 1) * n;
+        const float4 c = *reinterpret_cast<const float4*>(src + i0);
+        const float4 u = *reinterpret_cast<const float4*>(src + iu);
+        const float4 w = *reinterpret_cast<const float4*>(src + id);
+        C[pl][0] = src[lf ? i0 - 1 : i0];
+        C[pl][5] = src[rt ? i0 + 4 : i0];
+        C[pl][1] = c.x; C[pl][2] = c.y; C[pl][3] = c.z; C[pl][4] = c.w;
+        U[pl][0] = u.x; U[pl][1] = u.y; U[pl][2] = u.z; U[pl][3] = u.w;
+        D[pl][0] = w.x; D[pl][1] = w.y; D[pl][2] = w.z; D[pl][3] = w.w;
+      }
+      float Gv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dc = C[0][e + 1] * inv;
+        const float c0 = C[1][e + 1], c1 = C[2][e + 1], c2 = C[3][e + 1];
+        auto edge = [&](float n0, float n1, float n2) -> float {  // exp(-mean_c |I(i) - I(j)|)
+          const float m = (fabsf(c0 - n0) + fabsf(c1 - n1) + fabsf(c2 - n2)) * kThird;
+          return __expf(-m);
+        };
+        float G = 0.f;
+        if (e < 3 || rt) {
+          const float a = dc - C[0][e + 2] * inv, w = edge(C[1][e + 2], C[2][e + 2], C[3][e + 2]);
+          lx += fabsf(a) * w;
+          G += sgn(a) * w * icx;
+        }
+        if (e > 0 || lf) {
+          const float a = C[0][e] * inv - dc, w = edge(C[1][e], C[2][e], C[3][e]);
+          G -= sgn(a) * w * icx;
+        }
+        if (dn) {
+          const float a = dc - D[0][e] * inv, w = edge(D[1][e], D[2][e], D[3][e]);
+          ly += fabsf(a) * w;
+          G += sgn(a) * w * icy;
+        }
+        if (up) {
+          const float a = U[0][e] * inv - dc, w = edge(U[1][e], U[2][e], U[3][e]);
+          G -= sgn(a) * w * icy;
+        }
+        Gv[e] = G;
+        if (GRAD) gd = fmaf(G, C[0][e + 1], gd);
+      }
+      if (GRAD)
+        *reinterpret_cast<float4*>(p.sm_G + p.L.pix_off[s] + (long)b * n + i0) =
+            make_float4(Gv[0], Gv[1], Gv[2], Gv[3]);
+    }
+  } else
   for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
     const long i = (long)chunk * SM_PX + k;
     if (i >= n) break;
@@ -1005,7 +1066,6 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
       const float m = (fabsf(c0 - I[j]) + fabsf(c1 - I[n + j]) + fabsf(c2 - I[2 * n + j])) * kThird;
       return __expf(-m);
     };
-    auto sgn = [](float a) -> float { return (a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f); };
     if (x + 1 < ws) {
       const float a = dc - d[i + 1] * inv, w = edge(i + 1);
       lx += fabsf(a) * w;
@@ -1333,11 +1393,13 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.S = desc->S;
   p.tilesX = with_grad ? tc.gX : tc.fX;
   p.tilesY = with_grad ? tc.gY : tc.fY;
+  p.vec4 = 1;
   for (int s = 0; s < desc->S; ++s) {
     if (!disp[s] || !color_pyr[s]) return DW_ERR_NULL;
     p.disp[s] = disp[s];
     p.pyr[s] = color_pyr[s];
     p.mask[s] = mask ? mask[s] : nullptr;
+    if (((desc->W >> s) & 3) || (((uintptr_t)disp[s] | (uintptr_t)color_pyr[s]) & 15)) p.vec4 = 0;
   }
   for (int i = 0; i < 3; ++i) {
     if (!color[i]) return DW_ERR_NULL;
@@ -1402,6 +1464,7 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
     p.disp[s] = disp[s];
     p.grad_disp[s] = grad_disp[s];
   }
+
   p.K = K;
   p.grad_loss = grad_loss;
   const char* ws = (const char*)workspace;
