@@ -1175,14 +1175,22 @@ struct BwdParams {
   const float* sm_part;
   float* grad_disp[DW_MAX_SCALES];
   float* grad_T;
+  // grid of grad_disp_kernel: pixels per block, blocks per image and block offset of every scale
+  int g_ppb[DW_MAX_SCALES], g_nblk[DW_MAX_SCALES], g_off[DW_MAX_SCALES + 1];
   ScaleLayout L;
 };
 
 __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
   __shared__ float red[SM_NT / kWave + 1];
   __shared__ float s_gd;
-  int s, b, chunk;
-  decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
+  // Full resolution is a plain map (1024 pixels per block, four per thread); the
+  // coarser scales gather tile partials per pixel, which is several times the
+  // work, and take one pixel per thread.
+  int s = 0;
+  while (s + 1 < p.S && (int)blockIdx.x >= p.g_off[s + 1]) ++s;
+  const int rblk = blockIdx.x - p.g_off[s];
+  const int b = rblk / p.g_nblk[s], chunk = rblk - b * p.g_nblk[s];
+  const int ppb = p.g_ppb[s];
   const int hs = p.L.Hs[s], ws = p.L.Ws[s];
   const long n = (long)hs * ws;
   const int H = p.H, W = p.W;
@@ -1207,8 +1215,8 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
   const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
   const int ntile = p.tilesX * p.tilesY;
   const int pc_max = part_cols(s);
-  for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
-    const long i = (long)chunk * SM_PX + k;
+  for (int k = threadIdx.x; k < ppb; k += SM_NT) {
+    const long i = (long)chunk * ppb + k;
     if (i >= n) break;
     // 32-bit index arithmetic (n < 2^30): a 64-bit division costs more than the rest of the pixel
     const int y = (int)((unsigned)i / (unsigned)ws), x = (int)((unsigned)i - (unsigned)y * (unsigned)ws);
@@ -1476,7 +1484,13 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   p.sm_part = (const float*)(ws + w.sm_part);
   p.grad_T = grad_T;
   hipStream_t st = (hipStream_t)stream;
-  grad_disp_kernel<<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
+  p.g_off[0] = 0;
+  for (int s = 0; s < DW_MAX_SCALES; ++s) {
+    p.g_ppb[s] = (s == 0) ? SM_PX : SM_NT;
+    p.g_nblk[s] = (s < p.S) ? (p.L.Hs[s] * p.L.Ws[s] + p.g_ppb[s] - 1) / p.g_ppb[s] : 0;
+    p.g_off[s + 1] = p.g_off[s] + p.B * p.g_nblk[s];
+  }
+  grad_disp_kernel<<<p.g_off[p.S], SM_NT, 0, st>>>(p);
   if (grad_T) grad_pose_kernel<<<p.B, GP_NT, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
