@@ -21,13 +21,13 @@
 // tiles in a fixed order, add the smoothness term and scale by the upstream
 // gradient.  No atomics anywhere: results are bitwise reproducible.
 //
-// Tile geometry.  A block owns an "error-map region" Q of QH x 64 pixels, one
-// 1xSW strip per thread (NT = QH * 64/SW threads).  The colour / warped region R is
+// Tile geometry.  A block owns an "error-map region" Q of QH x QW pixels, one
+// 1xSW strip per thread (NT = QH * QW/SW threads).  The colour / warped region R is
 // Q plus one pixel on every side (3x3 SSIM window).  With gradients, the pixels
 // a block is responsible for (its "core") are Q minus one pixel on every side,
 // because the adjoint of the window sums at a pixel needs the error terms of
-// its eight neighbours; tiles therefore step by (QH-2) x 62.  Forward-only
-// blocks have core = Q and step by QH x 64.
+// its eight neighbours; tiles therefore step by (QH-2) x (QW-2).  Forward-only
+// blocks have core = Q and step by QH x QW.
 #include "dw_common.h"
 
 namespace dw {
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           wx[q][1] = 1.f;
           wx[q][2] = (x == W - 2) ? 2.f : 1.f;
         }
-        // winning frame of the 3x6 neighbourhood (Q rows qr-1..qr+1, cols 4ql-1..4ql+4)
+        // winning frame of the 3 x WW neighbourhood (Q rows qr-1..qr+1, cols SW*ql-1..SW*ql+SW)
         int nsel[3][WW];
         const int gwin = (qr - 1) * RP + SW * ql;
 #pragma unroll
