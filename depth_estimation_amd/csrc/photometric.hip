@@ -766,46 +766,69 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         float gdepth[SW];
 #pragma unroll
         for (int q = 0; q < SW; ++q) gdepth[q] = 0.f;
+        // Window-sum adjoint, one colour channel (three coefficient planes) at a
+        // time and both frames in the same pass over LDS: `tot` is the sum over
+        // all neighbours, `af0` over the neighbours where frame 0 won; frame 1's
+        // sum is their difference (the planes are zero where no frame won).
+        // d err / d (sample position) accumulates per frame in gix / giy.
+        float gix[2][SW], giy[2][SW];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          // window-sum adjoint of frame f: column sums over the three rows, then
-          // the three columns of each pixel
-          float acc[SW][9];
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            float g[3][WW], cs[WW];
+          for (int q = 0; q < SW; ++q) gix[f][q] = giy[f][q] = 0.f;
+        // weights of the frame-0 neighbours (row weight times mask), shared by the nine planes
+        float w0[3][WW];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) loadw(&s_un[k * GN + gwin + r * RP], g[r]);
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int j = 0; j < WW; ++j) w0[r][j] = (nsel[r][j] == 0) ? wy[r] : 0.f;
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+          float tot[SW][3], af0[SW][3];
+#pragma unroll
+          for (int k3 = 0; k3 < 3; ++k3) {
+            float g[3][WW], cs[WW], cs0[WW];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) loadw(&s_un[(3 * c + k3) * GN + gwin + r * RP], g[r]);
 #pragma unroll
             for (int j = 0; j < WW; ++j) {
-              const float a0 = (nsel[0][j] == f) ? g[0][j] : 0.f;
-              const float a1 = (nsel[1][j] == f) ? g[1][j] : 0.f;
-              const float a2 = (nsel[2][j] == f) ? g[2][j] : 0.f;
-              cs[j] = fmaf(wy[0], a0, fmaf(wy[2], a2, a1));
+              cs[j] = fmaf(wy[0], g[0][j], fmaf(wy[2], g[2][j], g[1][j]));
+              cs0[j] = fmaf(w0[0][j], g[0][j], fmaf(w0[2][j], g[2][j], w0[1][j] * g[1][j]));
             }
 #pragma unroll
-            for (int q = 0; q < SW; ++q)
-              acc[q][k] = fmaf(wx[q][0], cs[q], fmaf(wx[q][2], cs[q + 2], cs[q + 1]));
+            for (int q = 0; q < SW; ++q) {
+              tot[q][k3] = fmaf(wx[q][0], cs[q], fmaf(wx[q][2], cs[q + 2], cs[q + 1]));
+              af0[q][k3] = fmaf(wx[q][0], cs0[q], fmaf(wx[q][2], cs0[q + 2], cs0[q + 1]));
+            }
           }
+#pragma unroll
+          for (int q = 0; q < SW; ++q) {
+            const float yq = s_tgt[c * RN + win + RP + 1 + q];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+              const float* st = &s_st[f * 9 * QH * QW + qr * QW + SW * ql + q];
+              const float a0 = f ? tot[q][0] - af0[q][0] : af0[q][0];
+              const float a1 = f ? tot[q][1] - af0[q][1] : af0[q][1];
+              const float a2 = f ? tot[q][2] - af0[q][2] : af0[q][2];
+              const float xq = st[c * QH * QW];
+              float gx = kNinth * (a0 + 2.0f * xq * a1 + yq * a2);
+              if (sel[q] == f) {
+                const float df = xq - yq;
+                gx += kWL1 * kThird * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
+              }
+              gix[f][q] = fmaf(gx, st[(c + 3) * QH * QW], gix[f][q]);
+              giy[f][q] = fmaf(gx, st[(c + 6) * QH * QW], giy[f][q]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
 #pragma unroll
           for (int q = 0; q < SW; ++q) {
             if (!(live[q] && any[f][q])) continue;
             const float X = depth[q] * r0[q], Y = depth[q] * r1[q], Z = depth[q] * r2[q];
             const float* P = f ? P1 : P0;
-            const float* st = &s_st[f * 9 * QH * QW + qr * QW + SW * ql + q];
-            float gix = 0.f, giy = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float xq = st[c * QH * QW], yq = s_tgt[c * RN + win + RP + 1 + q];
-              float gx = kNinth * (acc[q][3 * c] + 2.0f * xq * acc[q][3 * c + 1] +
-                                   yq * acc[q][3 * c + 2]);
-              if (sel[q] == f) {
-                const float df = xq - yq;
-                gx += kWL1 * kThird * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
-              }
-              gix = fmaf(gx, st[(c + 3) * QH * QW], gix);
-              giy = fmaf(gx, st[(c + 6) * QH * QW], giy);
-            }
             // projection of the pixel again (registers only: no memory access)
             const float c0 = fmaf(P[0], X, fmaf(P[1], Y, fmaf(P[2], Z, P[3])));
             const float c1 = fmaf(P[4], X, fmaf(P[5], Y, fmaf(P[6], Z, P[7])));
@@ -813,8 +836,8 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
             const float iz = __builtin_amdgcn_rcpf(c2 + kProjEps);
             const float pu = c0 * iz, pv = c1 * iz;
             const unsigned vbits = (unsigned)s_valid[win + RP + 1 + q] >> (6 * f);
-            const float gu = (vbits & 1) ? gix : 0.f;
-            const float gv = (vbits & 2) ? giy : 0.f;
+            const float gu = (vbits & 1) ? gix[f][q] : 0.f;
+            const float gv = (vbits & 2) ? giy[f][q] : 0.f;
             const float gc0 = gu * iz, gc1 = gv * iz;
             const float gc2 = -(gu * pu + gv * pv) * iz;
             dP[f][0] = fmaf(gc0, X, dP[f][0]);
