@@ -40,6 +40,42 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 constexpr int kSumLane = 63;
 
+// Exchange of register halves between two values (gfx950): after swap32 `a`
+// holds the lower 32 lanes of both inputs and `b` the upper 32; swap16 does the
+// same with the even / odd rows of 16 lanes.  (The builtins' result is converted
+// as a whole before an element is taken: element access on it is mis-compiled.)
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {
+  const dw_f2 r = __builtin_bit_cast(dw_f2, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
+                                                                             __builtin_bit_cast(unsigned, b), false, false));
+  a = r.x;
+  b = r.y;
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {
+  const dw_f2 r = __builtin_bit_cast(dw_f2, __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a),
+                                                                             __builtin_bit_cast(unsigned, b), false, false));
+  a = r.x;
+  b = r.y;
+}
+// Wave sums of four values in one register: afterwards every lane of row 0 / 1
+// / 2 / 3 (16 lanes each) holds the total of v0 / v2 / v1 / v3.  Two half
+// exchanges fold the 64 lanes of each value onto one row, four DPP steps sum
+// the row.  Fixed order: bitwise reproducible.
+__device__ __forceinline__ float wave_sum4_fold(float v0, float v1, float v2, float v3) {
+  lane_swap32(v0, v1);
+  lane_swap32(v2, v3);
+  float u = v0 + v1, w = v2 + v3;
+  lane_swap16(u, w);
+  return u + w;
+}
+__device__ __forceinline__ float row_sum(float t) {
+  t = dpp_add<0xb1, 0xf>(t);   // quad_perm:[1,0,3,2]
+  t = dpp_add<0x4e, 0xf>(t);   // quad_perm:[2,3,0,1]
+  t = dpp_add<0x124, 0xf>(t);  // row_ror:4
+  t = dpp_add<0x128, 0xf>(t);  // row_ror:8
+  return t;
+}
+
 // Sum over the block, in a fixed order (bitwise reproducible). The result is
 // valid in thread 0. `red` holds NT/64 floats. Contains two barriers.
 template <int NT>

@@ -863,29 +863,34 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
       }
       DW_STAMP(5)  // stage C
       // pose partials and the loss of this scale: one value per wave and entry.
-      // The six DPP steps are issued entry by entry, so that no step waits on
-      // the previous one.
+      // Four entries share a register (two half-wave exchanges fold each onto one
+      // row of 16 lanes), then four DPP steps sum the rows: 7 registers instead of
+      // 25 full six-step reductions.
       {
         const int lane = tid & (kWave - 1), wid = tid / kWave;
-        float v[25];
+        float v[28];
 #pragma unroll
         for (int k = 0; k < 24; ++k) v[k] = dP[k / 12][k % 12];
         v[24] = loss_acc;
+        v[25] = v[26] = v[27] = 0.f;
+        float t[7];
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0xb1, 0xf>(v[k]);   // quad_perm:[1,0,3,2]
+        for (int g = 0; g < 7; ++g) t[g] = wave_sum4_fold(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x4e, 0xf>(v[k]);   // quad_perm:[2,3,0,1]
+        for (int g = 0; g < 7; ++g) t[g] = dpp_add<0xb1, 0xf>(t[g]);   // quad_perm:[1,0,3,2]
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x124, 0xf>(v[k]);  // row_ror:4
+        for (int g = 0; g < 7; ++g) t[g] = dpp_add<0x4e, 0xf>(t[g]);   // quad_perm:[2,3,0,1]
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x128, 0xf>(v[k]);  // row_ror:8
+        for (int g = 0; g < 7; ++g) t[g] = dpp_add<0x124, 0xf>(t[g]);  // row_ror:4
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x142, 0xa>(v[k]);  // row_bcast:15
+        for (int g = 0; g < 7; ++g) t[g] = dpp_add<0x128, 0xf>(t[g]);  // row_ror:8
+        if ((lane & 15) == 0) {
+          // row 0 / 1 / 2 / 3 of register g holds entry 4g + 0 / 2 / 1 / 3
+          const int row = lane >> 4;
+          const int e = ((row & 1) << 1) | (row >> 1);
 #pragma unroll
-        for (int k = 0; k < 25; ++k) v[k] = dpp_add<0x143, 0xc>(v[k]);  // row_bcast:31 -> lane 63
-        if (lane == kSumLane) {
-#pragma unroll
-          for (int k = 0; k < 25; ++k) s_dPw[wid * 25 + k] = v[k];
+          for (int g = 0; g < 7; ++g)
+            if (4 * g + e < 25) s_dPw[wid * 25 + 4 * g + e] = t[g];
         }
       }
       // after the next barrier: per-tile sums over the waves, fixed order
