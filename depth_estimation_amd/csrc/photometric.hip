@@ -592,9 +592,15 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     float loss_acc = 0.f;
 
     DW_STAMP(0)
-    // ---- stage A: warp both sources over the region
+    // ---- stage A: warp both sources over the region.  The region is NFULL full
+    // passes of the block plus LEFT pixels; when the rest is small it is shared
+    // out over all waves with the two frames of a pixel in the two halves of a
+    // wave, so that no wave runs a nearly empty pass while the others wait.
+    constexpr int NFULL = (RH * RW) / NT, LEFT = RH * RW - NFULL * NT;
+    constexpr int LEFT_PER_WAVE = (LEFT + NT / kWave - 1) / (NT / kWave);
+    constexpr bool SPLIT_LEFT = LEFT > 0 && LEFT_PER_WAVE <= 32;
 #pragma unroll 1
-    for (int i0 = tid; i0 < RH * RW; i0 += NT) {
+    for (int i0 = tid; i0 < (SPLIT_LEFT ? NFULL * NT : RH * RW); i0 += NT) {
       int i = i0;
       asm volatile("" : "+v"(i));  // keep per-pixel geometry from being hoisted out of the scale loop
       const int ry = i / RW, rx = i - ry * RW;
@@ -638,6 +644,51 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         }
       }
       s_valid[li] = vb;
+    }
+    if (SPLIT_LEFT) {
+      const int lane = tid & (kWave - 1);
+      const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+      const int h = lane & 31, f = lane >> 5;  // pixel slot of the wave, source frame
+      const int pi = wid * LEFT_PER_WAVE + h;
+      const bool act = h < LEFT_PER_WAVE && pi < LEFT;
+      int i = NFULL * NT + (act ? pi : 0);
+      asm volatile("" : "+v"(i));
+      const int ry = i / RW, rx = i - ry * RW;
+      const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
+      const int li = ry * RP + rx;
+      const float depth = s_depth[s * RN + li];
+      const float fx = (float)x, fy = (float)y;
+      const float X = depth * ((iK[0] * fx + iK[1] * fy) + iK[2]);
+      const float Y = depth * ((iK[3] * fx + iK[4] * fy) + iK[5]);
+      const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
+      float Pf[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Pf[k] = f ? P1[k] : P0[k];
+      const float* srcf = f ? src_b[1] : src_b[0];
+      SampleAddr ad;
+      SampleTaps tp;
+      Sample sm;
+      sample_addr(H, W, Pf, X, Y, Z, ad);
+      sample_gather(srcf, plane, ad, tp);
+      sample_blend<GRAD>(ad, tp, sm);
+      unsigned vb = (sm.valid ? 1u : 0u) << (2 + f);
+      if (GRAD) vb |= ((sm.inx ? 1u : 0u) | (sm.iny ? 2u : 0u)) << (6 * f);
+      const unsigned other = (unsigned)__shfl_xor((int)vb, 32, kWave);  // the other frame's bits of this pixel
+      if (act) {
+        s_un[(f * 3 + 0) * RN + li] = sm.val[0];
+        s_un[(f * 3 + 1) * RN + li] = sm.val[1];
+        s_un[(f * 3 + 2) * RN + li] = sm.val[2];
+        if (GRAD && ry >= 1 && ry <= QH && rx >= 1 && rx <= QW) {
+          float* st = &s_st[f * 9 * QH * QW + (ry - 1) * QW + (rx - 1)];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            st[(c + 0) * QH * QW] = sm.val[c];
+            st[(c + 3) * QH * QW] = sm.dx[c];
+            st[(c + 6) * QH * QW] = sm.dy[c];
+          }
+        }
+        if (f == 0) s_valid[li] = (unsigned char)(vb | other);
+      }
     }
     DW_STAMP(1)  // stage A
     __syncthreads();
