@@ -52,6 +52,10 @@ constexpr int RW = QW + 2;   // region columns
 constexpr int RP = QW + 4;  // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
 constexpr int SM_NT = 256;
+#ifndef DW_GD_PASSES
+#define DW_GD_PASSES 2
+#endif
+constexpr int GD_PASSES = DW_GD_PASSES;  // coarse-scale pixels per lane group in grad_disp_kernel
 #ifndef DW_XCD_SWIZZLE
 #define DW_XCD_SWIZZLE 1
 #endif
@@ -68,19 +72,11 @@ struct Geom {
 };
 constexpr int G_CH = Geom<true>::CH, G_CW = Geom<true>::CW;
 
-// Largest number of low-resolution rows / columns of scale s that the core of
-// one gradient tile can touch through the bilinear up-sampling taps.
-__host__ __device__ constexpr int part_rows(int s) { return (G_CH - 1) / (1 << s) + 3; }
-__host__ __device__ constexpr int part_cols(int s) { return (G_CW - 1) / (1 << s) + 3; }
-__host__ __device__ constexpr int part_size(int s) { return part_rows(s) * part_cols(s); }
-constexpr int MAX_TMP = G_CH * part_cols(1);
-
 struct ScaleLayout {
   int Hs[DW_MAX_SCALES], Ws[DW_MAX_SCALES];
   int nblk[DW_MAX_SCALES];          // blocks per image at scale s (map kernels)
   int blk_off[DW_MAX_SCALES + 1];   // prefix sum of B * nblk[s]
   long pix_off[DW_MAX_SCALES + 1];  // prefix sum of B * Hs * Ws
-  long part_off[DW_MAX_SCALES + 1]; // prefix sum of B * tiles * part_size(s), s >= 1
 };
 
 struct PhotoParams {
@@ -100,8 +96,8 @@ struct PhotoParams {
   float* sum_part;   // [blk_off[S]]            partial sums of disp[s]
   float* tile_loss;  // [B][tiles][4]
   float* tile_dP;    // [B][tiles][S][24]
-  float* gd0;        // [B][H][W]               d loss / d disp[0], photometric part
-  float* part;       // [part_off[S]]           per-tile up-sampling adjoint partials, s >= 1
+  float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
+  float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
   float* sm_part;    // [blk_off[S]][3]
   ScaleLayout L;
@@ -287,7 +283,7 @@ __device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
 
 // Diagnostic build only (-DDW_STAMPS): per-wave cycle sums of the kernel's
 // segments, taken with s_memtime. The sums of one tile overwrite the start of
-// the gd0 workspace section, so that build's gradients are not usable.
+// the gdup workspace section, so that build's gradients are not usable.
 #ifdef DW_STAMPS
 #define DW_STAMP_DECL                               \
   unsigned long long t_last, t_acc[10];             \
@@ -318,16 +314,12 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   // [9][GN] during stage C (written after every thread is done with A-B data)
   __shared__ __attribute__((aligned(16))) float s_un[GRAD ? UNION : 6 * RN];
   __shared__ float s_depth[DW_MAX_SCALES * RN];  // depth of every region pixel at every scale
-  // d loss / d disp_up of the tile (stage D, scales >= 1) reuses the depth plane of scale 0
-  float* const s_gd = s_depth;
-  static_assert(!GRAD || QH * QW <= RN, "s_gd must fit one depth plane");
   // per error-map pixel and frame: warped colour (3), its x / y derivatives (3 + 3); stage A -> C
   __shared__ __attribute__((aligned(16))) float s_st[GRAD ? 2 * 9 * QH * QW : 4];
   // per region pixel: bits 2,3 validity of source 0,1, bits 0,1 / 6,7 sample strictly inside the
   // image in x,y for source 0 / 1 (stage A); bits 4,5 winning frame + 1
   // (stage B; 0 = no re-projection won, or not a pixel of the error map)
   __shared__ __attribute__((aligned(8))) unsigned char s_valid[RN];
-  __shared__ float s_tmp[GRAD ? MAX_TMP : 1];
   __shared__ float s_P[2][12];
   __shared__ float s_invK[9];
   __shared__ float s_red[NT / kWave];
@@ -956,53 +948,20 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
             p.tile_loss[tslot * DW_MAX_SCALES + s] = v;
         }
       };
-      if (s == 0) {
-        if (row_core) {
+      // d loss / d (up-sampled disparity) of the core pixels; the adjoint of the
+      // up-sampling itself is a gather in grad_disp_kernel
+      if (row_core) {
+        float* gout = p.gdup + ((long)s * p.B + b) * plane + (long)sy_img * W;
 #pragma unroll
-          for (int q = 0; q < SW; ++q) {
-            const int x = sx_img + q, qc = SW * ql + q;
-            if (qc >= CO && qc < QW - CO && x < W)
-              p.gd0[(long)b * plane + (long)sy_img * W + x] = gd[q];
-          }
-        }
-        __syncthreads();  // also separates this scale's LDS traffic from the next stage A
-        finish_sums();
-      } else {
-        // ---- stage D: adjoint of the bilinear up-sampling, restricted to this
-        // tile's core; rows first, then columns (both from LDS)
-        #pragma unroll
-        for (int q = 0; q < SW; ++q) s_gd[qr * QW + SW * ql + q] = gd[q];
-        __syncthreads();
-        finish_sums();
-        const int Y1 = min(cy0 + CH, H) - 1, X1 = min(cx0 + CW, W) - 1;
-        const int k2 = 1 << s;
-        const int ilo = upsample_taps(cy0, hs, sy).i0, ihi = upsample_taps(Y1, hs, sy).i1;
-        const int jlo = upsample_taps(cx0, ws, sx).i0, jhi = upsample_taps(X1, ws, sx).i1;
-        const int nrow = ihi - ilo + 1, ncol = jhi - jlo + 1, nY = Y1 - cy0 + 1;
-        const int pc_max = part_cols(s);
-        for (int e = tid; e < nY * ncol; e += NT) {
-          const int yr = e / ncol, jj = e - yr * ncol, j = jlo + jj;
-          const int Xa = max(cx0, (j - 1) * k2 + k2 / 2), Xb = min(X1, (j + 1) * k2 + k2 / 2 - 1);
-          float a = 0.f;
-#pragma unroll 4
-          for (int X = Xa; X <= Xb; ++X)
-            a = fmaf(upsample_weight(X, j, ws, sx), s_gd[(yr + CO) * QW + (X - cx0 + CO)], a);
-          s_tmp[yr * pc_max + jj] = a;
-        }
-        __syncthreads();
-        float* part = p.part + p.L.part_off[s] + tslot * part_size(s);
-        for (int e = tid; e < nrow * ncol; e += NT) {
-          const int ii = e / ncol, jj = e - ii * ncol, i = ilo + ii;
-          const int Ya = max(cy0, (i - 1) * k2 + k2 / 2), Yb = min(Y1, (i + 1) * k2 + k2 / 2 - 1);
-          float a = 0.f;
-#pragma unroll 4
-          for (int Y = Ya; Y <= Yb; ++Y)
-            a = fmaf(upsample_weight(Y, i, hs, sy), s_tmp[(Y - cy0) * pc_max + jj], a);
-          part[ii * pc_max + jj] = a;
+        for (int q = 0; q < SW; ++q) {
+          const int x = sx_img + q, qc = SW * ql + q;
+          if (qc >= CO && qc < QW - CO && x < W) gout[x] = gd[q];
         }
       }
+      __syncthreads();  // also separates this scale's LDS traffic from the next stage A
+      finish_sums();
     }
-    DW_STAMP(6)  // pose partials + stage D
+    DW_STAMP(6)  // pose partials, gradient store
     if (!GRAD) {
       // per-tile partial sum (fixed order: reproducible run to run); its barriers
       // also separate this scale's LDS traffic from the next stage A
@@ -1013,7 +972,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   }
 #ifdef DW_STAMPS
   if (GRAD && (tid & 63) == 0 && tile == p.tilesX * (p.tilesY / 2) + p.tilesX / 2 && b == p.B / 2 && s_lo == 0)
-    for (int k = 0; k < 10; ++k) p.gd0[(tid / 64) * 10 + k] = (float)t_acc[k];
+    for (int k = 0; k < 10; ++k) p.gdup[(tid / 64) * 10 + k] = (float)t_acc[k];
 #endif
 }
 
@@ -1217,6 +1176,23 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
     if (lane == 0) s_part[k][wid] = a;
   }
+  // per image (scale, sample): mean of disp and sum of G * disp, from the per-block
+  // partials; read by grad_disp_kernel, which then needs no reduction of its own
+  for (int m = wid; m < p.S * p.B; m += 1024 / kWave) {
+    const int s = m / p.B, b = m - s * p.B;
+    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = lane; k < p.L.nblk[s]; k += kWave) {
+      a0 += p.sum_part[base + k];
+      a1 += p.sm_part[(base + k) * 3 + 2];
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == kSumLane) {
+      p.img_scal[2 * m + 0] = a0 / (float)((long)p.L.Hs[s] * p.L.Ws[s]);
+      p.img_scal[2 * m + 1] = a1;
+    }
+  }
   __syncthreads();
   if (tid < 3 * DW_MAX_SCALES) {  // thread k finishes sum k
     double a = 0.0;
@@ -1248,8 +1224,8 @@ struct BwdParams {
   const float* grad_loss;
   const float* sum_part;
   const float* tile_dP;
-  const float* gd0;
-  const float* part;
+  const float* gdup;
+  const float* img_scal;
   const float* sm_G;
   const float* sm_part;
   float* grad_disp[DW_MAX_SCALES];
@@ -1260,11 +1236,10 @@ struct BwdParams {
 };
 
 __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
-  __shared__ float red[SM_NT / kWave + 1];
-  __shared__ float s_gd;
-  // Full resolution is a plain map (1024 pixels per block, four per thread); the
-  // coarser scales gather tile partials per pixel, which is several times the
-  // work, and take one pixel per thread.
+  // Full resolution is a plain map (1024 pixels per block, four per thread).  A
+  // coarser scale s gathers the adjoint of the bilinear up-sampling from the
+  // full-resolution gradient map: a pixel receives from 2 * 2^s columns, one lane
+  // per column, summed over the lanes with DPP (fixed order).
   int s = 0;
   while (s + 1 < p.S && (int)blockIdx.x >= p.g_off[s + 1]) ++s;
   const int rblk = blockIdx.x - p.g_off[s];
@@ -1274,52 +1249,54 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
   const long n = (long)hs * ws;
   const int H = p.H, W = p.W;
   const long plane = (long)H * W;
-  const float mean = image_mean(p.sum_part, p.L, s, b, red);
-  {  // sum_i G_i * disp_i over the whole image, from the per-block partials
-    float a = 0.f;
-    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
-    for (int k = threadIdx.x; k < p.L.nblk[s]; k += SM_NT) a += p.sm_part[(base + k) * 3 + 2];
-    const float t = block_sum<SM_NT>(a, red);
-    if (threadIdx.x == 0) s_gd = t;
-    __syncthreads();
-  }
+  const float mean = p.img_scal[2 * (s * p.B + b) + 0];
+  const float sum_gd = p.img_scal[2 * (s * p.B + b) + 1];  // sum_i G_i * disp_i over the image
   const float go = p.grad_loss[0];
   const float inv = 1.0f / (mean + kMeanEps);
   const float coef = go * (kWSmooth / (float)(1 << s)) / (float)p.S;
   const float g0 = go / ((float)p.S * (float)p.B * (float)plane);
-  const float mean_term = s_gd * inv * inv / (float)n;
+  const float mean_term = sum_gd * inv * inv / (float)n;
   const float* G = p.sm_G + p.L.pix_off[s] + (long)b * n;
+  const float* gup = p.gdup + ((long)s * p.B + b) * plane;
   float* out = p.grad_disp[s] + (long)b * n;
-  const int k2 = 1 << s;
-  const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
-  const int ntile = p.tilesX * p.tilesY;
-  const int pc_max = part_cols(s);
-  for (int k = threadIdx.x; k < ppb; k += SM_NT) {
-    const long i = (long)chunk * ppb + k;
-    if (i >= n) break;
-    // 32-bit index arithmetic (n < 2^30): a 64-bit division costs more than the rest of the pixel
-    const int y = (int)((unsigned)i / (unsigned)ws), x = (int)((unsigned)i - (unsigned)y * (unsigned)ws);
-    float ph = 0.f;
-    if (s == 0) {
-      ph = p.gd0[(long)b * plane + i];
-    } else {
-      // every tile whose core holds a full-resolution pixel with a tap at (y, x)
-      const int Ya = max(0, (y - 1) * k2 + k2 / 2), Yb = min(H - 1, (y + 1) * k2 + k2 / 2 - 1);
-      const int Xa = max(0, (x - 1) * k2 + k2 / 2), Xb = min(W - 1, (x + 1) * k2 + k2 / 2 - 1);
-      for (int tY = Ya / G_CH; tY <= Yb / G_CH; ++tY) {
-        const int cy0 = tY * G_CH, Y1 = min(cy0 + G_CH, H) - 1;
-        const int ilo = upsample_taps(cy0, hs, sy).i0, ihi = upsample_taps(Y1, hs, sy).i1;
-        if (y < ilo || y > ihi) continue;
-        for (int tX = Xa / G_CW; tX <= Xb / G_CW; ++tX) {
-          const int cx0 = tX * G_CW, X1 = min(cx0 + G_CW, W) - 1;
-          const int jlo = upsample_taps(cx0, ws, sx).i0, jhi = upsample_taps(X1, ws, sx).i1;
-          if (x < jlo || x > jhi) continue;
-          const long slot = (long)b * ntile + (long)tY * p.tilesX + tX;
-          ph += p.part[p.L.part_off[s] + slot * part_size(s) + (y - ilo) * pc_max + (x - jlo)];
-        }
-      }
+  if (s == 0) {
+    for (int k = threadIdx.x; k < ppb; k += SM_NT) {
+      const long i = (long)chunk * ppb + k;
+      if (i >= n) break;
+      out[i] = coef * (G[i] * inv - mean_term) + g0 * gup[i];
     }
-    out[i] = coef * (G[i] * inv - mean_term) + g0 * ph;
+    return;
+  }
+  const int k2 = 1 << s;
+  const int lp_shift = s + 1;  // lanes per pixel = 2 * 2^s <= 16: groups never straddle a DPP row
+  const int r = threadIdx.x & ((1 << lp_shift) - 1);
+  const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
+  // GD_PASSES pixels per lane group, one after the other (fewer, longer blocks)
+  for (int pass = 0; pass < GD_PASSES; ++pass) {
+    const int pix = pass * (SM_NT >> lp_shift) + (threadIdx.x >> lp_shift);
+    const long i = (long)chunk * ppb + pix;
+    const bool act = i < n;
+    const long ic = act ? i : 0;
+    // 32-bit index arithmetic (n < 2^30)
+    const int y = (int)((unsigned)ic / (unsigned)ws), x = (int)((unsigned)ic - (unsigned)y * (unsigned)ws);
+    // full-resolution rows / columns with a bilinear tap at (y, x)
+    const int Ya = max(0, (y - 1) * k2 + k2 / 2), Yb = min(H - 1, (y + 1) * k2 + k2 / 2 - 1);
+    const int Xa = max(0, (x - 1) * k2 + k2 / 2), Xb = min(W - 1, (x + 1) * k2 + k2 / 2 - 1);
+    // lane r takes column Xa + r and walks down the rows: the lanes of a pixel, and
+    // of its neighbours in the wave, read one contiguous run per row
+    const int X = Xa + r;
+    float acc = 0.f;
+    if (act && X <= Xb) {
+      const float* col = gup + X;
+#pragma unroll 4
+      for (int Y = Ya; Y <= Yb; ++Y) acc = fmaf(upsample_weight(Y, y, hs, sy), col[(long)Y * W], acc);
+      acc *= upsample_weight(X, x, ws, sx);
+    }
+    acc = dpp_add<0xb1, 0xf>(acc);                // quad_perm:[1,0,3,2]
+    acc = dpp_add<0x4e, 0xf>(acc);                // quad_perm:[2,3,0,1]
+    if (s >= 2) acc = dpp_add<0x141, 0xf>(acc);   // row_half_mirror: 8 lanes
+    if (s >= 3) acc = dpp_add<0x140, 0xf>(acc);   // row_mirror: 16 lanes
+    if (act && r == 0) out[i] = coef * (G[i] * inv - mean_term) + g0 * acc;
   }
 }
 
@@ -1357,7 +1334,7 @@ __global__ __launch_bounds__(GP_NT) void grad_pose_kernel(const BwdParams p) {
 
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t sum_part, tile_loss, tile_dP, gd0, part, sm_G, sm_part, total;
+  size_t sum_part, tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, total;
 };
 
 struct TileCounts {
@@ -1374,7 +1351,6 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   const size_t tiles_max = tiles_g > (size_t)tc.fX * tc.fY ? tiles_g : (size_t)tc.fX * tc.fY;
   L.blk_off[0] = 0;
   L.pix_off[0] = 0;
-  L.part_off[0] = 0;
   for (int s = 0; s < DW_MAX_SCALES; ++s) {
     if (s < d.S) {
       L.Hs[s] = d.H >> s;
@@ -1386,8 +1362,6 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
     }
     L.blk_off[s + 1] = L.blk_off[s] + d.B * L.nblk[s];
     L.pix_off[s + 1] = L.pix_off[s] + (long)d.B * L.Hs[s] * L.Ws[s];
-    L.part_off[s + 1] =
-        L.part_off[s] + ((s >= 1 && s < d.S) ? (long)d.B * tiles_g * part_size(s) : 0);
   }
   const size_t A = 256;
   size_t o = 0;
@@ -1401,10 +1375,10 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S] * 3, A);
   w.sm_G = o;
   o = align_up(o + sizeof(float) * (size_t)L.pix_off[d.S], A);
-  w.part = o;
-  o = align_up(o + sizeof(float) * (size_t)L.part_off[d.S], A);
-  w.gd0 = o;
-  o = align_up(o + sizeof(float) * (size_t)d.B * d.H * d.W, A);
+  w.img_scal = o;
+  o = align_up(o + sizeof(float) * (size_t)DW_MAX_SCALES * d.B * 2, A);
+  w.gdup = o;  // last section (the diagnostic stamps overwrite its start)
+  o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
   w.total = o;
 }
 
@@ -1500,8 +1474,8 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.sum_part = (float*)(ws + w.sum_part);
   p.tile_loss = (float*)(ws + w.tile_loss);
   p.tile_dP = (float*)(ws + w.tile_dP);
-  p.gd0 = (float*)(ws + w.gd0);
-  p.part = (float*)(ws + w.part);
+  p.gdup = (float*)(ws + w.gdup);
+  p.img_scal = (float*)(ws + w.img_scal);
   p.sm_G = (float*)(ws + w.sm_G);
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
@@ -1557,15 +1531,15 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   const char* ws = (const char*)workspace;
   p.sum_part = (const float*)(ws + w.sum_part);
   p.tile_dP = (const float*)(ws + w.tile_dP);
-  p.gd0 = (const float*)(ws + w.gd0);
-  p.part = (const float*)(ws + w.part);
+  p.gdup = (const float*)(ws + w.gdup);
+  p.img_scal = (const float*)(ws + w.img_scal);
   p.sm_G = (const float*)(ws + w.sm_G);
   p.sm_part = (const float*)(ws + w.sm_part);
   p.grad_T = grad_T;
   hipStream_t st = (hipStream_t)stream;
   p.g_off[0] = 0;
   for (int s = 0; s < DW_MAX_SCALES; ++s) {
-    p.g_ppb[s] = (s == 0) ? SM_PX : SM_NT;
+    p.g_ppb[s] = (s == 0) ? SM_PX : GD_PASSES * (SM_NT / (2 << s));  // coarse scales: 2 * 2^s lanes per pixel
     p.g_nblk[s] = (s < p.S) ? (p.L.Hs[s] * p.L.Ws[s] + p.g_ppb[s] - 1) / p.g_ppb[s] : 0;
     p.g_off[s + 1] = p.g_off[s] + p.B * p.g_nblk[s];
   }

@@ -8,7 +8,7 @@ for _ in range(3): plan.forward(True)
 torch.cuda.synchronize()
 # gd0 is the last workspace section: B*H*W floats
 ws = plan.ws.view(torch.float32)
-gd0 = ws[-12*192*640:]
+gd0 = ws[-4*12*192*640:]
 t = gd0[:40].cpu().view(4, 10)
 names = ["loop head", "A", "barrier after A", "B", "G planes + barriers", "C", "pose partials + D", "loss sum", "prologue loads", "ystat + identity"]
 print("per-wave cycles (rows=waves):")
