@@ -52,6 +52,9 @@ constexpr int RW = QW + 2;   // region columns
 constexpr int RP = QW + 4;  // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
 constexpr int SM_NT = 256;
+#ifndef DW_PIPE_A
+#define DW_PIPE_A 1
+#endif
 #ifndef DW_GD_PASSES
 #define DW_GD_PASSES 2
 #endif
@@ -591,41 +594,48 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
     constexpr int NFULL = (RH * RW) / NT, LEFT = RH * RW - NFULL * NT;
     constexpr int LEFT_PER_WAVE = (LEFT + NT / kWave - 1) / (NT / kWave);
     constexpr bool SPLIT_LEFT = LEFT > 0 && LEFT_PER_WAVE <= 32;
-#pragma unroll 1
-    for (int i0 = tid; i0 < (SPLIT_LEFT ? NFULL * NT : RH * RW); i0 += NT) {
-      int i = i0;
+    struct Px {
+      int li, sti;
+      bool stash, act;
+      int f;
+    };
+    // issue: geometry, projection into both frames and all 24 taps of region pixel i
+    auto setup = [&](int i, Px& q, SampleAddr* qa, SampleTaps* qt) __attribute__((always_inline)) {
       asm volatile("" : "+v"(i));  // keep per-pixel geometry from being hoisted out of the scale loop
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
-      const int li = ry * RP + rx;
-      const float depth = s_depth[s * RN + li];
+      q.li = ry * RP + rx;
+      q.stash = ry >= 1 && ry <= QH && rx >= 1 && rx <= QW;
+      q.sti = (ry - 1) * QW + (rx - 1);
+      const float depth = s_depth[s * RN + q.li];
       const float fx = (float)x, fy = (float)y;
       const float X = depth * ((iK[0] * fx + iK[1] * fy) + iK[2]);
       const float Y = depth * ((iK[3] * fx + iK[4] * fy) + iK[5]);
       const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
-      unsigned char vb = 0;
       // both frames' taps are in flight before the first blend: frame 1 is
       // projected while the loads of frame 0 travel
-      SampleAddr ad[2];
-      SampleTaps tp[2];
-      sample_addr(H, W, P0, X, Y, Z, ad[0]);
-      sample_gather(src_b[0], plane, ad[0], tp[0]);
+      sample_addr(H, W, P0, X, Y, Z, qa[0]);
+      sample_gather(src_b[0], plane, qa[0], qt[0]);
       __builtin_amdgcn_sched_barrier(0);
-      sample_addr(H, W, P1, X, Y, Z, ad[1]);
-      sample_gather(src_b[1], plane, ad[1], tp[1]);
+      sample_addr(H, W, P1, X, Y, Z, qa[1]);
+      sample_gather(src_b[1], plane, qa[1], qt[1]);
       __builtin_amdgcn_sched_barrier(0);
+    };
+    // consume: blend, warped images / stash / status byte to LDS
+    auto finish = [&](const Px& q, const SampleAddr* qa, const SampleTaps* qt) __attribute__((always_inline)) {
+      unsigned char vb = 0;
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         Sample sm;
-        sample_blend<GRAD>(ad[f], tp[f], sm);
-        s_un[(f * 3 + 0) * RN + li] = sm.val[0];
-        s_un[(f * 3 + 1) * RN + li] = sm.val[1];
-        s_un[(f * 3 + 2) * RN + li] = sm.val[2];
+        sample_blend<GRAD>(qa[f], qt[f], sm);
+        s_un[(f * 3 + 0) * RN + q.li] = sm.val[0];
+        s_un[(f * 3 + 1) * RN + q.li] = sm.val[1];
+        s_un[(f * 3 + 2) * RN + q.li] = sm.val[2];
         vb |= (sm.valid ? 1 : 0) << (2 + f);
         if (GRAD) {
           vb |= ((sm.inx ? 1 : 0) | (sm.iny ? 2 : 0)) << (6 * f);
-          if (ry >= 1 && ry <= QH && rx >= 1 && rx <= QW) {
-            float* st = &s_st[f * 9 * QH * QW + (ry - 1) * QW + (rx - 1)];
+          if (q.stash) {
+            float* st = &s_st[f * 9 * QH * QW + q.sti];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               st[(c + 0) * QH * QW] = sm.val[c];
@@ -635,43 +645,48 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           }
         }
       }
-      s_valid[li] = vb;
-    }
-    if (SPLIT_LEFT) {
+      s_valid[q.li] = vb;
+    };
+    // the same for the shared-out rest: one frame of one pixel per lane
+    auto setup_left = [&](Px& q, SampleAddr& qa, SampleTaps& qt) __attribute__((always_inline)) {
       const int lane = tid & (kWave - 1);
       const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
-      const int h = lane & 31, f = lane >> 5;  // pixel slot of the wave, source frame
+      const int h = lane & 31;  // pixel slot of the wave
+      q.f = lane >> 5;          // source frame
       const int pi = wid * LEFT_PER_WAVE + h;
-      const bool act = h < LEFT_PER_WAVE && pi < LEFT;
-      int i = NFULL * NT + (act ? pi : 0);
+      q.act = h < LEFT_PER_WAVE && pi < LEFT;
+      int i = NFULL * NT + (q.act ? pi : 0);
       asm volatile("" : "+v"(i));
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
-      const int li = ry * RP + rx;
-      const float depth = s_depth[s * RN + li];
+      q.li = ry * RP + rx;
+      q.stash = ry >= 1 && ry <= QH && rx >= 1 && rx <= QW;
+      q.sti = (ry - 1) * QW + (rx - 1);
+      const float depth = s_depth[s * RN + q.li];
       const float fx = (float)x, fy = (float)y;
       const float X = depth * ((iK[0] * fx + iK[1] * fy) + iK[2]);
       const float Y = depth * ((iK[3] * fx + iK[4] * fy) + iK[5]);
       const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
       float Pf[12];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) Pf[k] = f ? P1[k] : P0[k];
-      const float* srcf = f ? src_b[1] : src_b[0];
-      SampleAddr ad;
-      SampleTaps tp;
+      for (int k = 0; k < 12; ++k) Pf[k] = q.f ? P1[k] : P0[k];
+      const float* srcf = q.f ? src_b[1] : src_b[0];
+      sample_addr(H, W, Pf, X, Y, Z, qa);
+      sample_gather(srcf, plane, qa, qt);
+    };
+    auto finish_left = [&](const Px& q, const SampleAddr& qa, const SampleTaps& qt) __attribute__((always_inline)) {
+      const int f = q.f;
       Sample sm;
-      sample_addr(H, W, Pf, X, Y, Z, ad);
-      sample_gather(srcf, plane, ad, tp);
-      sample_blend<GRAD>(ad, tp, sm);
+      sample_blend<GRAD>(qa, qt, sm);
       unsigned vb = (sm.valid ? 1u : 0u) << (2 + f);
       if (GRAD) vb |= ((sm.inx ? 1u : 0u) | (sm.iny ? 2u : 0u)) << (6 * f);
       const unsigned other = (unsigned)__shfl_xor((int)vb, 32, kWave);  // the other frame's bits of this pixel
-      if (act) {
-        s_un[(f * 3 + 0) * RN + li] = sm.val[0];
-        s_un[(f * 3 + 1) * RN + li] = sm.val[1];
-        s_un[(f * 3 + 2) * RN + li] = sm.val[2];
-        if (GRAD && ry >= 1 && ry <= QH && rx >= 1 && rx <= QW) {
-          float* st = &s_st[f * 9 * QH * QW + (ry - 1) * QW + (rx - 1)];
+      if (q.act) {
+        s_un[(f * 3 + 0) * RN + q.li] = sm.val[0];
+        s_un[(f * 3 + 1) * RN + q.li] = sm.val[1];
+        s_un[(f * 3 + 2) * RN + q.li] = sm.val[2];
+        if (GRAD && q.stash) {
+          float* st = &s_st[f * 9 * QH * QW + q.sti];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             st[(c + 0) * QH * QW] = sm.val[c];
@@ -679,7 +694,39 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
             st[(c + 6) * QH * QW] = sm.dy[c];
           }
         }
-        if (f == 0) s_valid[li] = (unsigned char)(vb | other);
+        if (f == 0) s_valid[q.li] = (unsigned char)(vb | other);
+      }
+    };
+    if (DW_PIPE_A && SPLIT_LEFT && NFULL == 2) {
+      // software pipeline: the taps of the next pixel are in flight while the
+      // current one is blended and stored
+      Px q0, q1, ql;
+      SampleAddr a0[2], a1[2], al;
+      SampleTaps t0[2], t1[2], tl;
+      setup(tid, q0, a0, t0);
+      setup(tid + NT, q1, a1, t1);
+      finish(q0, a0, t0);
+      __builtin_amdgcn_sched_barrier(0);
+      setup_left(ql, al, tl);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(q1, a1, t1);
+      __builtin_amdgcn_sched_barrier(0);
+      finish_left(ql, al, tl);
+    } else {
+#pragma unroll 1
+      for (int i0 = tid; i0 < (SPLIT_LEFT ? NFULL * NT : RH * RW); i0 += NT) {
+        Px q;
+        SampleAddr qa[2];
+        SampleTaps qt[2];
+        setup(i0, q, qa, qt);
+        finish(q, qa, qt);
+      }
+      if (SPLIT_LEFT) {
+        Px q;
+        SampleAddr qa;
+        SampleTaps qt;
+        setup_left(q, qa, qt);
+        finish_left(q, qa, qt);
       }
     }
     DW_STAMP(1)  // stage A
