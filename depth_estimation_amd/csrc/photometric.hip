@@ -128,16 +128,32 @@ __device__ __forceinline__ float upsample_weight(int dst, int j, int in_size, fl
   return fmaxf(0.f, 1.0f - fabsf(src - (float)j));
 }
 
-// Load from a uniform base pointer plus a 32-bit per-lane byte offset.
-__device__ __forceinline__ float tap(const float* base, unsigned byte_off) {
-  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+// Load from a base pointer plus a 32-bit per-lane byte offset.  With the base in
+// scalar registers this is one load with no per-lane 64-bit address arithmetic.
+typedef const __attribute__((address_space(1))) char* GlobalBytes;
+typedef const __attribute__((address_space(1))) float* GlobalFloats;
+__device__ __forceinline__ float tap(GlobalFloats base, unsigned byte_off) {
+  return *(GlobalFloats)((GlobalBytes)base + byte_off);
+}
+
+// A pointer that is the same in every lane, moved to scalar registers (64-bit
+// products of uniform values are computed by the vector unit and would
+// otherwise stay there, and every load through them pays a 64-bit add).
+// Off by default: with the bases in scalar registers the tile kernel spills
+// more scalar registers than it saves vector instructions (measured 1 % slower).
+#ifndef DW_UNIFORM_PTR
+#define DW_UNIFORM_PTR 0
+#endif
+__device__ __forceinline__ GlobalFloats uniform_ptr(const float* ptr) {
+  if (!DW_UNIFORM_PTR) return (GlobalFloats)ptr;
+  const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (GlobalFloats)(((unsigned long long)hi << 32) | lo);
 }
 
 struct Sample {
   float val[3];
-  bool valid;
-  float u, v, zp;
-  bool inx, iny;
   float dx[3], dy[3];  // d val[c] / d (sample x, y) in pixels, before the border mask
 };
 
@@ -147,8 +163,12 @@ struct Sample {
 struct SampleAddr {
   unsigned o_nw, o_ne, o_sw, o_se;  // byte offsets of the four taps inside a colour plane
   float tx, ty;                     // fractional position inside the cell
-  bool valid, inx, iny;
-  float u, v, zp;
+  // status bits of the sample, already at their place in the region's status byte
+  // for source frame f: bit 2 + f inside the image before clamping and in front of
+  // the camera; bits 6f, 6f + 1 strictly inside the image in x, y (the clamp is
+  // inactive, so the sample position has a gradient).  Kept as one integer: a
+  // boolean that lives across other work costs a pair of scalar registers.
+  unsigned vb;
 };
 struct SampleTaps {
   float nw[3], ne[3], sw[3], se[3];
@@ -156,8 +176,9 @@ struct SampleTaps {
 
 // Project the camera-space point (X,Y,Z) with P (3x4, row-major); border
 // padding, corners aligned.
+template <bool WITH_GRAD>
 __device__ __forceinline__ void sample_addr(int H, int W, const float* P, float X, float Y, float Z,
-                                            SampleAddr& a) {
+                                            unsigned f, SampleAddr& a) {
   const float c0 = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3];
   const float c1 = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7];
   const float c2 = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11];
@@ -167,11 +188,14 @@ __device__ __forceinline__ void sample_addr(int H, int W, const float* P, float 
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   const float gx = (u / wm1 - 0.5f) * 2.0f;
   const float gy = (v / hm1 - 0.5f) * 2.0f;
-  a.valid = (gx >= -1.f) && (gx <= 1.f) && (gy >= -1.f) && (gy <= 1.f) && (c2 > 0.f);
+  const bool valid = (gx >= -1.f) && (gx <= 1.f) && (gy >= -1.f) && (gy <= 1.f) && (c2 > 0.f);
+  a.vb = valid ? (4u << f) : 0u;
   float ix = ((gx + 1.0f) * 0.5f) * wm1;
   float iy = ((gy + 1.0f) * 0.5f) * hm1;
-  a.inx = (ix > 0.f) && (ix < wm1);
-  a.iny = (iy > 0.f) && (iy < hm1);
+  if (WITH_GRAD) {
+    a.vb |= ((ix > 0.f) && (ix < wm1)) ? (1u << (6u * f)) : 0u;
+    a.vb |= ((iy > 0.f) && (iy < hm1)) ? (2u << (6u * f)) : 0u;
+  }
   ix = fminf(fmaxf(ix, 0.f), wm1);
   iy = fminf(fmaxf(iy, 0.f), hm1);
   const float ix0 = floorf(ix), iy0 = floorf(iy);
@@ -183,17 +207,14 @@ __device__ __forceinline__ void sample_addr(int H, int W, const float* P, float 
   a.o_ne = (unsigned)(y0 * W + x1) * 4u;
   a.o_sw = (unsigned)(y1 * W + x0) * 4u;
   a.o_se = (unsigned)(y1 * W + x1) * 4u;
-  a.u = u;
-  a.v = v;
-  a.zp = zp;
 }
 
 // uniform plane base + 32-bit per-lane offset: no 64-bit address arithmetic per tap
-__device__ __forceinline__ void sample_gather(const float* __restrict__ src, long plane,
+__device__ __forceinline__ void sample_gather(GlobalFloats src, long plane,
                                               const SampleAddr& a, SampleTaps& t) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float* p = src + c * plane;
+    const GlobalFloats p = src + c * plane;
     t.nw[c] = tap(p, a.o_nw);
     t.ne[c] = tap(p, a.o_ne);
     t.sw[c] = tap(p, a.o_sw);
@@ -215,12 +236,6 @@ __device__ __forceinline__ void sample_blend(const SampleAddr& a, const SampleTa
       o.dy[c] = fmaf(se - ne, tx, (sw - nw) * ex);
     }
   }
-  o.valid = a.valid;
-  o.inx = a.inx;
-  o.iny = a.iny;
-  o.u = a.u;
-  o.v = a.v;
-  o.zp = a.zp;
 }
 
 // The WW consecutive 32-bit words of one window row in LDS (start aligned to SW words).
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   // image in x,y for source 0 / 1 (stage A); bits 4,5 winning frame + 1
   // (stage B; 0 = no re-projection won, or not a pixel of the error map)
   __shared__ __attribute__((aligned(8))) unsigned char s_valid[RN];
-  __shared__ float s_P[2][12];
+  __shared__ __attribute__((aligned(16))) float s_P[2][12];
   __shared__ float s_invK[9];
   __shared__ float s_red[NT / kWave];
   // per-wave partial sums of one scale: 24 pose entries and the loss
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   const int qy0 = cy0 - CO, qx0 = cx0 - CO;      // ... of Q(0,0)
   const int ry0 = qy0 - 1, rx0 = qx0 - 1;        // ... of R(0,0)
   const int H = p.H, W = p.W;
-  const long plane = (long)H * W;
+  const long plane = H * W;  // 32-bit product (the host checks H * W <= 2^28): stays in scalar registers
   const int qr = tid / SPR, ql = tid % SPR;      // this thread's strip: Q row, Q cols SW*ql..
   const int win = qr * RP + SW * ql;              // region index of the strip's window corner
 
@@ -377,8 +392,9 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   }
 
   // ---- colour regions (reflect-mapped): target and the two un-warped sources
-  const float* tgt_b = p.color[0] + (long)b * 3 * plane;
-  const float* src_b[2] = {p.color[1] + (long)b * 3 * plane, p.color[2] + (long)b * 3 * plane};
+  const GlobalFloats tgt_b = uniform_ptr(p.color[0] + (long)b * 3 * plane);
+  const GlobalFloats src_b[2] = {uniform_ptr(p.color[1] + (long)b * 3 * plane),
+                           uniform_ptr(p.color[2] + (long)b * 3 * plane)};
   // Every global load of the prologue is issued before the first one is used
   // (nothing else is live yet, so registers are plentiful): all region pixels
   // of the thread, nine colour values and the four disparity taps of every
@@ -398,31 +414,31 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
       i = act ? i : 0;
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
-      const long o = (long)y * W + x;
+      const unsigned o = (unsigned)(y * W + x) * 4u;  // byte offset inside a plane
       lis[it] = act ? ry * RP + rx : -1;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        col[it][c] = tgt_b[c * plane + o];
-        col[it][3 + c] = src_b[0][c * plane + o];
-        col[it][6 + c] = src_b[1][c * plane + o];
+        col[it][c] = tap(tgt_b + c * plane, o);
+        col[it][3 + c] = tap(src_b[0] + c * plane, o);
+        col[it][6 + c] = tap(src_b[1] + c * plane, o);
       }
 #pragma unroll
       for (int s = 0; s < DW_MAX_SCALES; ++s) {
         const int sc = (s >= s_lo && s < s_hi) ? s : s_lo;
         const int hs = H >> sc, ws = W >> sc;
-        const float* d = p.disp[sc] + (long)b * hs * ws;
+        const GlobalFloats d = uniform_ptr(p.disp[sc] + (long)b * hs * ws);
         if (sc == 0) {  // uniform: scale 0 is not up-sampled
-          const float v = d[o];
+          const float v = tap(d, o);
           tapv[it][s][0] = tapv[it][s][1] = tapv[it][s][2] = tapv[it][s][3] = v;
           wy0[it][s] = wx0[it][s] = 1.f;
           wy1[it][s] = wx1[it][s] = 0.f;
         } else {
           const Taps ty = upsample_taps(y, hs, (float)hs / (float)H);
           const Taps tx = upsample_taps(x, ws, (float)ws / (float)W);
-          tapv[it][s][0] = d[(long)ty.i0 * ws + tx.i0];
-          tapv[it][s][1] = d[(long)ty.i0 * ws + tx.i1];
-          tapv[it][s][2] = d[(long)ty.i1 * ws + tx.i0];
-          tapv[it][s][3] = d[(long)ty.i1 * ws + tx.i1];
+          tapv[it][s][0] = tap(d, (unsigned)(ty.i0 * ws + tx.i0) * 4u);
+          tapv[it][s][1] = tap(d, (unsigned)(ty.i0 * ws + tx.i1) * 4u);
+          tapv[it][s][2] = tap(d, (unsigned)(ty.i1 * ws + tx.i0) * 4u);
+          tapv[it][s][3] = tap(d, (unsigned)(ty.i1 * ws + tx.i1) * 4u);
           wy0[it][s] = ty.l0;
           wy1[it][s] = ty.l1;
           wx0[it][s] = tx.l0;
@@ -614,10 +630,10 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
       const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
       // both frames' taps are in flight before the first blend: frame 1 is
       // projected while the loads of frame 0 travel
-      sample_addr(H, W, P0, X, Y, Z, qa[0]);
+      sample_addr<GRAD>(H, W, P0, X, Y, Z, 0u, qa[0]);
       sample_gather(src_b[0], plane, qa[0], qt[0]);
       __builtin_amdgcn_sched_barrier(0);
-      sample_addr(H, W, P1, X, Y, Z, qa[1]);
+      sample_addr<GRAD>(H, W, P1, X, Y, Z, 1u, qa[1]);
       sample_gather(src_b[1], plane, qa[1], qt[1]);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -631,9 +647,8 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         s_un[(f * 3 + 0) * RN + q.li] = sm.val[0];
         s_un[(f * 3 + 1) * RN + q.li] = sm.val[1];
         s_un[(f * 3 + 2) * RN + q.li] = sm.val[2];
-        vb |= (sm.valid ? 1 : 0) << (2 + f);
+        vb |= qa[f].vb;
         if (GRAD) {
-          vb |= ((sm.inx ? 1 : 0) | (sm.iny ? 2 : 0)) << (6 * f);
           if (q.stash) {
             float* st = &s_st[f * 9 * QH * QW + q.sti];
 #pragma unroll
@@ -670,16 +685,15 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
       float Pf[12];
 #pragma unroll
       for (int k = 0; k < 12; ++k) Pf[k] = q.f ? P1[k] : P0[k];
-      const float* srcf = q.f ? src_b[1] : src_b[0];
-      sample_addr(H, W, Pf, X, Y, Z, qa);
+      const GlobalFloats srcf = q.f ? src_b[1] : src_b[0];
+      sample_addr<GRAD>(H, W, Pf, X, Y, Z, (unsigned)q.f, qa);
       sample_gather(srcf, plane, qa, qt);
     };
     auto finish_left = [&](const Px& q, const SampleAddr& qa, const SampleTaps& qt) __attribute__((always_inline)) {
       const int f = q.f;
       Sample sm;
       sample_blend<GRAD>(qa, qt, sm);
-      unsigned vb = (sm.valid ? 1u : 0u) << (2 + f);
-      if (GRAD) vb |= ((sm.inx ? 1u : 0u) | (sm.iny ? 2u : 0u)) << (6 * f);
+      const unsigned vb = qa.vb;
       const unsigned other = (unsigned)__shfl_xor((int)vb, 32, kWave);  // the other frame's bits of this pixel
       if (q.act) {
         s_un[(f * 3 + 0) * RN + q.li] = sm.val[0];
@@ -912,22 +926,34 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        // Branch-free: a pixel without a contribution runs the same arithmetic on
+        // zeros (its depth, its gradient and the reciprocal are zeroed), which adds
+        // exact zeros to the sums.  The projection matrix is read from LDS here --
+        // in scalar registers it would be live across the whole scale loop.
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
+          float P[12];
+          {
+            const float4 a = *reinterpret_cast<const float4*>(&s_P[f][0]);
+            const float4 bq = *reinterpret_cast<const float4*>(&s_P[f][4]);
+            const float4 c = *reinterpret_cast<const float4*>(&s_P[f][8]);
+            P[0] = a.x, P[1] = a.y, P[2] = a.z, P[3] = a.w;
+            P[4] = bq.x, P[5] = bq.y, P[6] = bq.z, P[7] = bq.w;
+            P[8] = c.x, P[9] = c.y, P[10] = c.z, P[11] = c.w;
+          }
 #pragma unroll
           for (int q = 0; q < SW; ++q) {
-            if (!(live[q] && any[f][q])) continue;
+            const bool on = live[q] && any[f][q];
             const float X = depth[q] * r0[q], Y = depth[q] * r1[q], Z = depth[q] * r2[q];
-            const float* P = f ? P1 : P0;
             // projection of the pixel again (registers only: no memory access)
             const float c0 = fmaf(P[0], X, fmaf(P[1], Y, fmaf(P[2], Z, P[3])));
             const float c1 = fmaf(P[4], X, fmaf(P[5], Y, fmaf(P[6], Z, P[7])));
             const float c2 = fmaf(P[8], X, fmaf(P[9], Y, fmaf(P[10], Z, P[11])));
-            const float iz = __builtin_amdgcn_rcpf(c2 + kProjEps);
+            const float iz = on ? __builtin_amdgcn_rcpf(c2 + kProjEps) : 0.f;
             const float pu = c0 * iz, pv = c1 * iz;
             const unsigned vbits = (unsigned)s_valid[win + RP + 1 + q] >> (6 * f);
-            const float gu = (vbits & 1) ? gix[f][q] : 0.f;
-            const float gv = (vbits & 2) ? giy[f][q] : 0.f;
+            const float gu = (on && (vbits & 1)) ? gix[f][q] : 0.f;
+            const float gv = (on && (vbits & 2)) ? giy[f][q] : 0.f;
             const float gc0 = gu * iz, gc1 = gv * iz;
             const float gc2 = -(gu * pu + gv * pv) * iz;
             dP[f][0] = fmaf(gc0, X, dP[f][0]);
