@@ -13,7 +13,7 @@
 // Launch sequence of one training step:
 //   forward : disp_sum_kernel -> photo_tile_kernel<GRAD> -> smooth_kernel
 //             -> loss_finalize_kernel
-//   backward: grad_disp_kernel -> grad_pose_kernel
+//   backward: backward_kernel (pose blocks + disparity-map blocks)
 // photo_tile_kernel<true> does the whole per-pixel backward at unit upstream
 // gradient while the tile is still on chip, including the adjoint of the
 // disparity up-sampling restricted to the tile, and leaves per-tile partial
@@ -58,7 +58,7 @@ constexpr int SM_NT = 256;
 #ifndef DW_GD_PASSES
 #define DW_GD_PASSES 2
 #endif
-constexpr int GD_PASSES = DW_GD_PASSES;  // coarse-scale pixels per lane group in grad_disp_kernel
+constexpr int GD_PASSES = DW_GD_PASSES;  // coarse-scale pixels per lane group in the backward kernel
 #ifndef DW_XCD_SWIZZLE
 #define DW_XCD_SWIZZLE 1
 #endif
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         }
       };
       // d loss / d (up-sampled disparity) of the core pixels; the adjoint of the
-      // up-sampling itself is a gather in grad_disp_kernel
+      // up-sampling itself is a gather in the backward kernel
       if (row_core) {
         float* gout = p.gdup + ((long)s * p.B + b) * plane + (long)sy_img * W;
 #pragma unroll
@@ -1101,7 +1101,6 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
   const long n = (long)hs * ws;
   const float* d = p.disp[s] + (long)b * n;
   const float* I = p.pyr[s] + (long)b * 3 * n;
-  const float inv = 1.0f / (image_mean(p.sum_part, p.L, s, b, red) + kMeanEps);
   const float icx = 1.0f / ((float)p.B * hs * (ws - 1));
   const float icy = 1.0f / ((float)p.B * (hs - 1) * ws);
   float lx = 0.f, ly = 0.f, gd = 0.f;
@@ -1111,24 +1110,29 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
     // row, reads them and their upper / lower neighbours as 16-byte vectors (a
     // missing neighbour row re-reads the centre row and is masked) and the two
     // pixels beside the group as scalars.  Same per-pixel arithmetic as below.
+    // The loads are issued before the image mean is reduced, so that the two
+    // latencies overlap (a thread past the end of the image re-reads its start).
     const long i0 = (long)chunk * SM_PX + 4 * threadIdx.x;
-    if (i0 < n) {
-      const int y = (int)((unsigned)i0 / (unsigned)ws), x0 = (int)((unsigned)i0 - (unsigned)y * (unsigned)ws);
-      const bool up = y > 0, dn = y + 1 < hs, lf = x0 > 0, rt = x0 + 4 < ws;
-      const long iu = up ? i0 - ws : i0, id = dn ? i0 + ws : i0;
-      float C[4][6], U[4][4], D[4][4];  // [plane: disp, I0, I1, I2][column]; C holds x0-1 .. x0+4
+    const bool act = i0 < n;
+    const long ia = act ? i0 : 0;
+    const int y = (int)((unsigned)ia / (unsigned)ws), x0 = (int)((unsigned)ia - (unsigned)y * (unsigned)ws);
+    const bool up = y > 0, dn = y + 1 < hs, lf = x0 > 0, rt = x0 + 4 < ws;
+    const long iu = up ? ia - ws : ia, id = dn ? ia + ws : ia;
+    float C[4][6], U[4][4], D[4][4];  // [plane: disp, I0, I1, I2][column]; C holds x0-1 .. x0+4
 #pragma unroll
-      for (int pl = 0; pl < 4; ++pl) {
-        const float* src = (pl == 0) ? d : I + (long)(pl - 1) * n;
-        const float4 c = *reinterpret_cast<const float4*>(src + i0);
-        const float4 u = *reinterpret_cast<const float4*>(src + iu);
-        const float4 w = *reinterpret_cast<const float4*>(src + id);
-        C[pl][0] = src[lf ? i0 - 1 : i0];
-        C[pl][5] = src[rt ? i0 + 4 : i0];
-        C[pl][1] = c.x; C[pl][2] = c.y; C[pl][3] = c.z; C[pl][4] = c.w;
-        U[pl][0] = u.x; U[pl][1] = u.y; U[pl][2] = u.z; U[pl][3] = u.w;
-        D[pl][0] = w.x; D[pl][1] = w.y; D[pl][2] = w.z; D[pl][3] = w.w;
-      }
+    for (int pl = 0; pl < 4; ++pl) {
+      const float* src = (pl == 0) ? d : I + (long)(pl - 1) * n;
+      const float4 c = *reinterpret_cast<const float4*>(src + ia);
+      const float4 u = *reinterpret_cast<const float4*>(src + iu);
+      const float4 w = *reinterpret_cast<const float4*>(src + id);
+      C[pl][0] = src[lf ? ia - 1 : ia];
+      C[pl][5] = src[rt ? ia + 4 : ia];
+      C[pl][1] = c.x; C[pl][2] = c.y; C[pl][3] = c.z; C[pl][4] = c.w;
+      U[pl][0] = u.x; U[pl][1] = u.y; U[pl][2] = u.z; U[pl][3] = u.w;
+      D[pl][0] = w.x; D[pl][1] = w.y; D[pl][2] = w.z; D[pl][3] = w.w;
+    }
+    const float inv = 1.0f / (image_mean(p.sum_part, p.L, s, b, red) + kMeanEps);
+    if (act) {
       float Gv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1164,7 +1168,8 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
         *reinterpret_cast<float4*>(p.sm_G + p.L.pix_off[s] + (long)b * n + i0) =
             make_float4(Gv[0], Gv[1], Gv[2], Gv[3]);
     }
-  } else
+  } else {
+  const float inv = 1.0f / (image_mean(p.sum_part, p.L, s, b, red) + kMeanEps);
   for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
     const long i = (long)chunk * SM_PX + k;
     if (i >= n) break;
@@ -1200,25 +1205,57 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
       gd = fmaf(G, d[i], gd);
     }
   }
-  float* out = p.sm_part + (long)blockIdx.x * 3;
-  float t = block_sum<SM_NT>(lx, red);
-  if (threadIdx.x == 0) out[0] = t;
-  t = block_sum<SM_NT>(ly, red);
-  if (threadIdx.x == 0) out[1] = t;
-  if (GRAD) {
-    t = block_sum<SM_NT>(gd, red);
-    if (threadIdx.x == 0) out[2] = t;
+  }
+  // the three block sums behind one pair of barriers; thread k adds the wave values of sum k
+  __shared__ float red3[3][SM_NT / kWave];
+  lx = wave_sum(lx);
+  ly = wave_sum(ly);
+  if (GRAD) gd = wave_sum(gd);
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  if (lane == kSumLane) {
+    red3[0][wid] = lx;
+    red3[1][wid] = ly;
+    if (GRAD) red3[2][wid] = gd;
+  }
+  __syncthreads();
+  if (threadIdx.x < (GRAD ? 3 : 2)) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_NT / kWave; ++i) t += red3[threadIdx.x][i];
+    p.sm_part[(long)blockIdx.x * 3 + threadIdx.x] = t;
   }
 }
 
 // ------------------------------------------------- scalar loss
-// One block of 1024 threads.  All 3*S sums (tile losses, smoothness x, y) are
-// accumulated in double in one pass over the partials (the S tile partials of a
-// tile are one 16-byte load), reduced per wave with shuffles and across waves
-// by one thread: fixed order.
+// Blocks of 1024 threads.  Block 0: all 3*S sums (tile losses, smoothness x, y)
+// are accumulated in double in one pass over the partials (the S tile partials
+// of a tile are one 16-byte load), reduced per wave with shuffles and across
+// waves by one thread: fixed order.  Blocks 1..: the per-image scalars of the
+// backward pass, one image per wave.
+constexpr int LF_WAVES = 1024 / kWave;
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p, float* loss_out) {
-  __shared__ double s_part[3 * DW_MAX_SCALES][1024 / kWave];
+  __shared__ double s_part[3 * DW_MAX_SCALES][LF_WAVES];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  if (blockIdx.x > 0) {
+    // per image (scale, sample): mean of disp and sum of G * disp, from the per-block
+    // partials; read by the backward kernel, which then needs no reduction of its own
+    const int m = ((int)blockIdx.x - 1) * LF_WAVES + wid;
+    if (m >= p.S * p.B) return;
+    const int s = m / p.B, b = m - s * p.B;
+    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = lane; k < p.L.nblk[s]; k += kWave) {
+      a0 += p.sum_part[base + k];
+      a1 += p.sm_part[(base + k) * 3 + 2];
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == kSumLane) {
+      p.img_scal[2 * m + 0] = a0 / (float)((long)p.L.Hs[s] * p.L.Ws[s]);
+      p.img_scal[2 * m + 1] = a1;
+    }
+    return;
+  }
   const int ntile = p.B * p.tilesX * p.tilesY;
   double acc[3 * DW_MAX_SCALES];
 #pragma unroll
@@ -1249,27 +1286,10 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
     if (lane == 0) s_part[k][wid] = a;
   }
-  // per image (scale, sample): mean of disp and sum of G * disp, from the per-block
-  // partials; read by grad_disp_kernel, which then needs no reduction of its own
-  for (int m = wid; m < p.S * p.B; m += 1024 / kWave) {
-    const int s = m / p.B, b = m - s * p.B;
-    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
-    float a0 = 0.f, a1 = 0.f;
-    for (int k = lane; k < p.L.nblk[s]; k += kWave) {
-      a0 += p.sum_part[base + k];
-      a1 += p.sm_part[(base + k) * 3 + 2];
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == kSumLane) {
-      p.img_scal[2 * m + 0] = a0 / (float)((long)p.L.Hs[s] * p.L.Ws[s]);
-      p.img_scal[2 * m + 1] = a1;
-    }
-  }
   __syncthreads();
   if (tid < 3 * DW_MAX_SCALES) {  // thread k finishes sum k
     double a = 0.0;
-    for (int w = 0; w < 1024 / kWave; ++w) a += s_part[tid][w];
+    for (int w = 0; w < LF_WAVES; ++w) a += s_part[tid][w];
     s_part[tid][0] = a;
   }
   __syncthreads();
@@ -1303,19 +1323,24 @@ struct BwdParams {
   const float* sm_part;
   float* grad_disp[DW_MAX_SCALES];
   float* grad_T;
-  // grid of grad_disp_kernel: pixels per block, blocks per image and block offset of every scale
+  // grid of backward_kernel: n_pose blocks for d loss / d T first, then the blocks
+  // of d loss / d disp[s] from the coarsest scale (the longest blocks) to the finest.
+  // Pixels per block and blocks per image of every scale; g_off[k] = first block of
+  // scale S - 1 - k, counted after the pose blocks
+  int n_pose;
   int g_ppb[DW_MAX_SCALES], g_nblk[DW_MAX_SCALES], g_off[DW_MAX_SCALES + 1];
   ScaleLayout L;
 };
 
-__global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
+__device__ __forceinline__ void grad_disp_block(const BwdParams& p, int blk) {
   // Full resolution is a plain map (1024 pixels per block, four per thread).  A
   // coarser scale s gathers the adjoint of the bilinear up-sampling from the
   // full-resolution gradient map: a pixel receives from 2 * 2^s columns, one lane
   // per column, summed over the lanes with DPP (fixed order).
-  int s = 0;
-  while (s + 1 < p.S && (int)blockIdx.x >= p.g_off[s + 1]) ++s;
-  const int rblk = blockIdx.x - p.g_off[s];
+  int k = 0;
+  while (k + 1 < p.S && blk >= p.g_off[k + 1]) ++k;
+  const int s = p.S - 1 - k;
+  const int rblk = blk - p.g_off[k];
   const int b = rblk / p.g_nblk[s], chunk = rblk - b * p.g_nblk[s];
   const int ppb = p.g_ppb[s];
   const int hs = p.L.Hs[s], ws = p.L.Ws[s];
@@ -1374,17 +1399,19 @@ __global__ __launch_bounds__(SM_NT) void grad_disp_kernel(const BwdParams p) {
 }
 
 // ------------------------------------------------- backward: d loss / d T
-constexpr int GP_NT = 1024, GP_GROUPS = GP_NT / 24;  // 42 groups of 24 threads (1008 in use)
-__global__ __launch_bounds__(GP_NT) void grad_pose_kernel(const BwdParams p) {
+// One block per sample sums the per-(tile, scale) partials of the projection
+// gradient in double, fixed order, and applies K^T.
+constexpr int GP_GROUPS = SM_NT / 24;  // 10 groups of 24 threads (240 of the 256 in use)
+__device__ __forceinline__ void grad_pose_block(const BwdParams& p, int b) {
   __shared__ double s_part[GP_GROUPS][24];
   __shared__ double s_dP[24];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int nrow = p.tilesX * p.tilesY * p.S;  // one row of 24 partials per (tile, scale)
   if (tid < GP_GROUPS * 24) {
     const int g = tid / 24, k = tid - g * 24;
     double a = 0.0;
     const float* src = p.tile_dP + (long)b * nrow * 24 + k;
-#pragma unroll 4
+#pragma unroll 8
     for (int t = g; t < nrow; t += GP_GROUPS) a += (double)src[(long)t * 24];
     s_part[g][k] = a;
   }
@@ -1403,6 +1430,15 @@ __global__ __launch_bounds__(GP_NT) void grad_pose_kernel(const BwdParams p) {
     const double g0 = (double)p.grad_loss[0] / ((double)p.S * p.B * p.H * p.W);
     p.grad_T[((long)b * DW_NUM_SRC + f) * 16 + k * 4 + j] = (float)(a * g0);
   }
+}
+
+// Both gradients in one launch: they are independent, and the few long pose
+// blocks run beside the many short map blocks instead of after them.
+__global__ __launch_bounds__(SM_NT) void backward_kernel(const BwdParams p) {
+  if ((int)blockIdx.x < p.n_pose)
+    grad_pose_block(p, blockIdx.x);
+  else
+    grad_disp_block(p, (int)blockIdx.x - p.n_pose);
 }
 
 // ------------------------------------------------------------- host side
@@ -1571,7 +1607,8 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
     photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
     smooth_kernel<false><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   }
-  loss_finalize_kernel<<<1, 1024, 0, st>>>(p, loss_out);
+  // without gradients nobody reads the per-image scalars: block 0 alone
+  loss_finalize_kernel<<<with_grad ? 1 + (p.S * p.B + LF_WAVES - 1) / LF_WAVES : 1, 1024, 0, st>>>(p, loss_out);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
 
@@ -1614,9 +1651,10 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   for (int s = 0; s < DW_MAX_SCALES; ++s) {
     p.g_ppb[s] = (s == 0) ? SM_PX : GD_PASSES * (SM_NT / (2 << s));  // coarse scales: 2 * 2^s lanes per pixel
     p.g_nblk[s] = (s < p.S) ? (p.L.Hs[s] * p.L.Ws[s] + p.g_ppb[s] - 1) / p.g_ppb[s] : 0;
-    p.g_off[s + 1] = p.g_off[s] + p.B * p.g_nblk[s];
   }
-  grad_disp_kernel<<<p.g_off[p.S], SM_NT, 0, st>>>(p);
-  if (grad_T) grad_pose_kernel<<<p.B, GP_NT, 0, st>>>(p);
+  for (int k = 0; k < DW_MAX_SCALES; ++k)
+    p.g_off[k + 1] = p.g_off[k] + (k < p.S ? p.B * p.g_nblk[p.S - 1 - k] : 0);
+  p.n_pose = grad_T ? p.B : 0;
+  backward_kernel<<<p.n_pose + p.g_off[p.S], SM_NT, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
