@@ -16,6 +16,9 @@ LIB_PATH = Path(os.environ.get("DEPTHWARP_LIB", _PKG / "libdepthwarp.so"))
 
 DW_MAX_SCALES = 4
 DW_NUM_SRC = 2
+DW_FLAG_TILE_KERNEL_ONLY = 1
+DW_FLAG_NO_TAIL_SPLIT = 2
+DW_FLAG_COLOR_GRAD = 4
 
 
 class DwDesc(C.Structure):
@@ -39,6 +42,7 @@ _SIGNATURES = {
                                      _VP, _VP, C.c_size_t, C.c_int, _VP]),
     "dw_photometric_bwd": (C.c_int, [C.POINTER(DwDesc), _PP, _VP, _VP, _VP, C.c_size_t, _PP, _VP,
                                      _VP]),
+    "dw_photometric_bwd_color": (C.c_int, [C.POINTER(DwDesc), _VP, _VP, C.c_size_t, _PP, _VP]),
     "dw_compute_loss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dw_compute_loss_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, _VP, C.c_size_t, _VP]),
     "dw_compute_loss_metrics_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, C.c_float, C.c_float, _VP, _VP,

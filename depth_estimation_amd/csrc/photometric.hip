@@ -15,11 +15,16 @@
 //             -> loss_finalize_kernel
 //   backward: backward_kernel (pose blocks + disparity-map blocks)
 // photo_tile_kernel<true> does the whole per-pixel backward at unit upstream
-// gradient while the tile is still on chip, including the adjoint of the
-// disparity up-sampling restricted to the tile, and leaves per-tile partial
-// sums in the workspace; the backward kernels add the partials of neighbouring
-// tiles in a fixed order, add the smoothness term and scale by the upstream
-// gradient.  No atomics anywhere: results are bitwise reproducible.
+// gradient while the tile is still on chip and leaves, per scale, the gradient
+// with respect to the up-sampled disparity (a full-resolution map) and per-tile
+// partial sums of the pose gradient in the workspace; the backward kernel
+// gathers the adjoint of the up-sampling, adds the partials in a fixed order,
+// adds the smoothness term and scales by the upstream gradient.  No
+// floating-point atomics anywhere: results are bitwise reproducible.  The
+// optional gradient with respect to the warped source images (flag
+// DW_FLAG_COLOR_GRAD, photo_tile_color_kernel) is a scatter; it accumulates in
+// 64-bit fixed point with integer atomics, which is independent of the order
+// of the additions and therefore reproducible as well.
 //
 // Tile geometry.  A block owns an "error-map region" Q of QH x QW pixels, one
 // 1xSW strip per thread (NT = QH * QW/SW threads).  The colour / warped region R is
@@ -100,6 +105,7 @@ struct PhotoParams {
   float* tile_loss;  // [B][tiles][4]
   float* tile_dP;    // [B][tiles][S][24]
   float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
+  unsigned long long* gcol;  // [2][B][3][H][W]  d loss / d (warped source image), 2^-32 fixed point; optional
   float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
   float* sm_part;    // [blk_off[S]][3]
@@ -320,8 +326,16 @@ __device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
 #endif
 
 // ------------------------------------------------------------ the tile kernel
-template <bool GRAD>
-__global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_kernel(const PhotoParams p) {
+// One contribution to a fixed-point sum: 2^-32 units, integer addition.
+__device__ __forceinline__ void atomic_add_fixed(unsigned long long* dst, float v) {
+  const long long q = (long long)(v * 4294967296.0f);
+  __hip_atomic_fetch_add(dst, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// GRAD: with the per-pixel backward.  CGRAD (needs GRAD): also scatter the
+// gradient with respect to the two warped source images into p.gcol.
+template <bool GRAD, bool CGRAD>
+__device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
   using Gm = Geom<GRAD>;
   constexpr int QH = Gm::QH, NT = Gm::NT, RH = Gm::RH, CO = Gm::CO, CH = Gm::CH, CW = Gm::CW;
   constexpr int RN = RH * RP;  // floats per region plane
@@ -880,6 +894,17 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int q = 0; q < SW; ++q) gix[f][q] = giy[f][q] = 0.f;
+        // where the pixel samples each source frame: the forward arithmetic again,
+        // bit for bit (same depth, same ray, same projection matrix)
+        SampleAddr ca[CGRAD ? 2 : 1][SW];
+        if (CGRAD) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int q = 0; q < SW; ++q)
+              sample_addr<false>(H, W, f ? P1 : P0, depth[q] * r0[q], depth[q] * r1[q], depth[q] * r2[q],
+                                 (unsigned)f, ca[CGRAD ? f : 0][q]);
+        }
         // weights of the frame-0 neighbours (row weight times mask), shared by the nine planes
         float w0[3][WW];
 #pragma unroll
@@ -922,6 +947,18 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
               }
               gix[f][q] = fmaf(gx, st[(c + 3) * QH * QW], gix[f][q]);
               giy[f][q] = fmaf(gx, st[(c + 6) * QH * QW], giy[f][q]);
+              if (CGRAD) {
+                // adjoint of the bilinear blend: gx goes to the four taps with their weights
+                if (live[q] && any[f][q]) {
+                  const SampleAddr& a = ca[CGRAD ? f : 0][q];
+                  unsigned long long* gc = p.gcol + (((long)f * p.B + b) * 3 + c) * plane;
+                  const float ex = 1.0f - a.tx, ey = 1.0f - a.ty;
+                  atomic_add_fixed(gc + (a.o_nw >> 2), gx * (ex * ey));
+                  atomic_add_fixed(gc + (a.o_ne >> 2), gx * (a.tx * ey));
+                  atomic_add_fixed(gc + (a.o_sw >> 2), gx * (ex * a.ty));
+                  atomic_add_fixed(gc + (a.o_se >> 2), gx * (a.tx * a.ty));
+                }
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -1047,6 +1084,14 @@ __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_k
   if (GRAD && (tid & 63) == 0 && tile == p.tilesX * (p.tilesY / 2) + p.tilesX / 2 && b == p.B / 2 && s_lo == 0)
     for (int k = 0; k < 10; ++k) p.gdup[(tid / 64) * 10 + k] = (float)t_acc[k];
 #endif
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_kernel(const PhotoParams p) {
+  photo_tile_body<GRAD, false>(p);
+}
+__global__ __launch_bounds__(Geom<true>::NT, Geom<true>::MINW) void photo_tile_color_kernel(const PhotoParams p) {
+  photo_tile_body<true, true>(p);
 }
 
 // Decode a block of the per-scale map kernels: scale, sample, chunk.
@@ -1441,9 +1486,26 @@ __global__ __launch_bounds__(SM_NT) void backward_kernel(const BwdParams p) {
     grad_disp_block(p, (int)blockIdx.x - p.n_pose);
 }
 
+// ------------------------------------------------- backward: d loss / d (warped sources)
+// Fixed-point sums of the tile kernel -> float gradients, scaled by the upstream
+// gradient and the 1 / (S * B * H * W) of the mean.
+__global__ __launch_bounds__(SM_NT) void grad_color_kernel(const long long* __restrict__ gcol,
+                                                           const float* __restrict__ grad_loss, float inv_count,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           long n_frame) {
+  const float g0 = grad_loss[0] * inv_count;
+  for (long i = (long)blockIdx.x * SM_NT + threadIdx.x; i < 2 * n_frame; i += (long)gridDim.x * SM_NT) {
+    const float v = (float)((double)gcol[i] * (1.0 / 4294967296.0));
+    if (i < n_frame)
+      out0[i] = g0 * v;
+    else
+      out1[i - n_frame] = g0 * v;
+  }
+}
+
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t sum_part, tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, total;
+  size_t sum_part, tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, gcol, total;
 };
 
 struct TileCounts {
@@ -1488,13 +1550,15 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   o = align_up(o + sizeof(float) * (size_t)DW_MAX_SCALES * d.B * 2, A);
   w.gdup = o;  // last section (the diagnostic stamps overwrite its start)
   o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
+  w.gcol = o;  // only with DW_FLAG_COLOR_GRAD
+  if (d.flags & DW_FLAG_COLOR_GRAD) o = align_up(o + sizeof(unsigned long long) * (size_t)2 * d.B * 3 * d.H * d.W, A);
   w.total = o;
 }
 
 static int check_desc(const dw_desc* d) {
   if (!d) return DW_ERR_NULL;
   if (d->B < 1 || d->S < 1 || d->S > DW_MAX_SCALES || d->F != DW_NUM_SRC) return DW_ERR_SHAPE;
-  if (d->flags & ~(DW_FLAG_TILE_KERNEL_ONLY | DW_FLAG_NO_TAIL_SPLIT)) return DW_ERR_ARG;
+  if (d->flags & ~(DW_FLAG_TILE_KERNEL_ONLY | DW_FLAG_NO_TAIL_SPLIT | DW_FLAG_COLOR_GRAD)) return DW_ERR_ARG;
   const int m = 1 << (d->S - 1);
   if (d->H % m || d->W % m) return DW_ERR_SHAPE;
   if ((d->H >> (d->S - 1)) < 2 || (d->W >> (d->S - 1)) < 2) return DW_ERR_SHAPE;
@@ -1588,12 +1652,19 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.sm_G = (float*)(ws + w.sm_G);
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
+  const bool cgrad = with_grad && (desc->flags & DW_FLAG_COLOR_GRAD);
+  if (cgrad) {
+    p.gcol = (unsigned long long*)(ws + w.gcol);
+    if (hipMemsetAsync(p.gcol, 0, w.total - w.gcol, st) != hipSuccess) return DW_ERR_LAUNCH;
+  }
 
   const int n_tiles = p.tilesX * p.tilesY * p.B;
   p.n_full = full_blocks(n_tiles, p.S, desc->flags);
   const dim3 tgrid(p.n_full + (n_tiles - p.n_full) * p.S);
   if (desc->flags & DW_FLAG_TILE_KERNEL_ONLY) {
-    if (with_grad)
+    if (cgrad)
+      photo_tile_color_kernel<<<tgrid, Geom<true>::NT, 0, st>>>(p);
+    else if (with_grad)
       photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
     else
       photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
@@ -1601,7 +1672,10 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   }
   disp_sum_kernel<<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   if (with_grad) {
-    photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
+    if (cgrad)
+      photo_tile_color_kernel<<<tgrid, Geom<true>::NT, 0, st>>>(p);
+    else
+      photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
     smooth_kernel<true><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   } else {
     photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
@@ -1656,5 +1730,26 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
     p.g_off[k + 1] = p.g_off[k] + (k < p.S ? p.B * p.g_nblk[p.S - 1 - k] : 0);
   p.n_pose = grad_T ? p.B : 0;
   backward_kernel<<<p.n_pose + p.g_off[p.S], SM_NT, 0, st>>>(p);
+  return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
+}
+
+extern "C" int dw_photometric_bwd_color(const dw_desc* desc, const float* grad_loss, const void* workspace,
+                                        size_t workspace_bytes, float* const* grad_color, void* stream) {
+  int rc = check_desc(desc);
+  if (rc != DW_OK) return rc;
+  if (!(desc->flags & DW_FLAG_COLOR_GRAD)) return DW_ERR_ARG;
+  if (!grad_loss || !workspace || !grad_color || !grad_color[0] || !grad_color[1]) return DW_ERR_NULL;
+  ScaleLayout L;
+  WsLayout w;
+  TileCounts tc;
+  make_layout(*desc, L, w, tc);
+  if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return DW_ERR_WORKSPACE;
+  const long n_frame = (long)desc->B * 3 * desc->H * desc->W;
+  const float inv_count = 1.0f / ((float)desc->S * (float)desc->B * (float)((long)desc->H * desc->W));
+  const long want = (2 * n_frame + SM_NT * 4 - 1) / (SM_NT * 4);
+  const int grid = (int)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
+  grad_color_kernel<<<grid, SM_NT, 0, (hipStream_t)stream>>>(
+      (const long long*)((const char*)workspace + w.gcol), grad_loss, inv_count, grad_color[0], grad_color[1],
+      n_frame);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }

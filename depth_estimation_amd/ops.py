@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import DwDesc, DW_NUM_SRC
+from ._lib import DwDesc, DW_NUM_SRC, DW_FLAG_COLOR_GRAD
 
 __all__ = ["photometric_stack", "photometric_forward", "workspace_bytes"]
 
@@ -39,8 +39,8 @@ def _desc_from(disp: Sequence[Tensor], color: Sequence[Tensor]) -> DwDesc:
     return DwDesc(B, H, W, len(disp), DW_NUM_SRC, 0)
 
 
-def workspace_bytes(B: int, H: int, W: int, S: int = 4) -> int:
-    d = DwDesc(B, H, W, S, DW_NUM_SRC, 0)
+def workspace_bytes(B: int, H: int, W: int, S: int = 4, flags: int = 0) -> int:
+    d = DwDesc(B, H, W, S, DW_NUM_SRC, flags)
     n = _lib.lib().dw_photometric_workspace_bytes(d)
     if n == 0:
         raise _lib.DepthwarpError(f"unsupported photometric-stack shape B={B} H={H} W={W} S={S}")
@@ -186,12 +186,17 @@ class PhotometricPlan:
     replayed from a HIP graph or issued back to back from a tight loop.  The
     autograd path above allocates its outputs per call instead; both run the
     same kernels.
+
+    With `flags=DW_FLAG_COLOR_GRAD` the forward pass also accumulates the
+    gradient with respect to the two source images as the warp samples them
+    (the scatter adjoint of the bilinear warp; the identity errors and the
+    target image are not differentiated) and `backward_color()` returns it.
     """
 
     def __init__(self, B: int, H: int, W: int, S: int = 4, device="cuda", flags: int = 0):
         self.desc = DwDesc(B, H, W, S, DW_NUM_SRC, flags)
         self.device = torch.device(device)
-        self.nbytes = workspace_bytes(B, H, W, S)
+        self.nbytes = workspace_bytes(B, H, W, S, flags)
         dev = self.device
         self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
         self.loss = torch.zeros(1 + 2 * S, dtype=torch.float32, device=dev)
@@ -202,6 +207,11 @@ class PhotometricPlan:
         self.one = torch.ones(1, dtype=torch.float32, device=dev)
         self._mask_ptrs = _lib.ptr_array([self.mask[s] for s in range(S)])
         self._gd_ptrs = _lib.ptr_array(self.grad_disp)
+        self.grad_color = None
+        if flags & DW_FLAG_COLOR_GRAD:
+            self.grad_color = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+                               for _ in range(DW_NUM_SRC)]
+            self._gc_ptrs = _lib.ptr_array(self.grad_color)
         self._lib = _lib.lib()
 
     def bind(self, disp, color, color_pyr, K, inv_K, T, tie_noise=None):
@@ -230,3 +240,15 @@ class PhotometricPlan:
                                           _stream(self.device) if stream is None else stream)
         _lib.check(rc, "dw_photometric_bwd")
         return self.grad_disp, self.grad_T
+
+    def backward_color(self, grad_loss: Optional[Tensor] = None, stream: Optional[int] = None):
+        """d loss / d (color[1], color[2]) through the warp; needs flags=DW_FLAG_COLOR_GRAD
+        and a preceding forward(with_grad=True)."""
+        if self.grad_color is None:
+            raise _lib.DepthwarpError("this plan was built without DW_FLAG_COLOR_GRAD")
+        g = self.one if grad_loss is None else grad_loss
+        rc = self._lib.dw_photometric_bwd_color(self.desc, g.data_ptr(), self.ws.data_ptr(), self.nbytes,
+                                                self._gc_ptrs,
+                                                _stream(self.device) if stream is None else stream)
+        _lib.check(rc, "dw_photometric_bwd_color")
+        return self.grad_color

@@ -68,6 +68,12 @@ typedef struct dw_desc {
 /* Testing only: never split the last tiles of the launch into per-scale blocks
  * (the split is a scheduling choice; results are identical with and without). */
 #define DW_FLAG_NO_TAIL_SPLIT 2
+/* Also accumulate the gradient with respect to the two source images as the
+ * warp samples them (the scatter adjoint of the bilinear warp; the identity
+ * errors and the target image are not differentiated).  The workspace grows by
+ * 48 * B * H * W bytes; read the result with dw_photometric_bwd_color.  Must be
+ * set identically for workspace_bytes, fwd (with_grad != 0) and the bwd calls. */
+#define DW_FLAG_COLOR_GRAD 4
 
 DW_API int dw_version(void);
 DW_API const char* dw_strerror(int code);
@@ -122,6 +128,21 @@ DW_API int dw_photometric_bwd(const dw_desc* desc,
                        const void* workspace, size_t workspace_bytes,
                        float* const* grad_disp,
                        float* grad_T,
+                       void* stream);
+
+/* Gradient of the loss with respect to the source images color[1], color[2] as
+ * sampled by the warp (the optional image gradient of the view-synthesis
+ * formulation; the reference, which has none of these stages, has no
+ * counterpart).  Requires DW_FLAG_COLOR_GRAD in desc->flags for this call and
+ * for the forward call that filled `workspace`.
+ *   grad_loss     device scalar, upstream gradient of the loss
+ *   grad_color    2 device pointers, (B,3,H,W) each, overwritten
+ * The sums behind it are accumulated in 64-bit fixed point (2^-32 units), so
+ * the result does not depend on the order of the additions. */
+DW_API int dw_photometric_bwd_color(const dw_desc* desc,
+                       const float* grad_loss,
+                       const void* workspace, size_t workspace_bytes,
+                       float* const* grad_color,
                        void* stream);
 
 /* ---------------------------------------------------------------------------

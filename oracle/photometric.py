@@ -237,7 +237,7 @@ def smooth_loss(disp, img):
 
 # --------------------------------------------------------------- whole stack
 def photometric_stack(disp, color, color_pyr, K, inv_K, T, tie_noise=None,
-                      return_aux=False):
+                      return_aux=False, warp_src=None):
     """
     disp       list of S tensors (B,1,H/2^s,W/2^s)
     color      list [target, source(-1), source(+1)], each (B,3,H,W)
@@ -245,6 +245,10 @@ def photometric_stack(disp, color, color_pyr, K, inv_K, T, tie_noise=None,
     K, inv_K   (B,4,4) pixel-unit intrinsics
     T          (B,F,4,4) target->source transforms, F = 2
     tie_noise  optional (B,F,H,W) added to the identity errors
+    warp_src   optional list of F tensors (B,3,H,W) sampled by the warp in place
+               of color[1:]; with the same values as color[1:] the loss is the
+               same, and its autograd gradient is the adjoint of the warp alone
+               (the identity errors keep reading color[1:])
     Returns the scalar loss (and a dict of per-scale maps when return_aux).
     """
     S = len(disp)
@@ -270,7 +274,7 @@ def photometric_stack(disp, color, color_pyr, K, inv_K, T, tie_noise=None,
         reproj, valids = [], []
         for f in range(nF):
             _, _, gx, gy, valid = project(depth, rays, P[f], H, W)
-            warped = warp_bilinear(color[1 + f], gx, gy)
+            warped = warp_bilinear(color[1 + f] if warp_src is None else warp_src[f], gx, gy)
             reproj.append(reprojection_error(warped, target))
             valids.append(valid)
         m, idx, gap = min_first(ident + reproj)

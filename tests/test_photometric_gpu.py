@@ -214,3 +214,63 @@ def test_parity_flat_inputs():
     seq.color = [seq.color[0].clone() for _ in range(3)]
     masks = _check_against_oracle(seq)
     assert int((masks & 3).max()) == 0
+
+
+def _oracle_color_grad(seq):
+    """Gradient of the oracle's loss w.r.t. the images the warp samples (copies of the two
+    sources that only the warp reads)."""
+    from oracle import photometric as ph
+    warp_src = [seq.color[1 + f].clone().requires_grad_(True) for f in range(2)]
+    loss = ph.photometric_stack(seq.disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, seq.T,
+                                seq.tie_noise, warp_src=warp_src)
+    loss.backward()
+    return [w.grad for w in warp_src]
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 96), (1, 48, 160), (2, 192, 640)])
+def test_color_gradient_matches_oracle(B, H, W):
+    """Optional gradient w.r.t. the warped source images (flag 4): the scatter adjoint of the
+    bilinear warp against autograd of the oracle, 1e-4 relative (max-norm); every other output
+    must be bitwise what the plan without the flag produces."""
+    from depth_estimation_amd.ops import PhotometricPlan
+    from depth_estimation_amd._lib import DW_FLAG_COLOR_GRAD
+    seq = make_sequence(B, H, W, seed=H + B)
+    want = _oracle_color_grad(seq)
+    g = seq.to("cuda")
+    plain = PhotometricPlan(B, H, W, 4, "cuda").bind(*g.args())
+    plain.forward(True)
+    plain.backward()
+    plan = PhotometricPlan(B, H, W, 4, "cuda", flags=DW_FLAG_COLOR_GRAD).bind(*g.args())
+    got = []
+    for _ in range(2):  # twice: the accumulators are cleared by every forward call
+        plan.forward(True)
+        plan.backward()
+        got.append([c.clone() for c in plan.backward_color()])
+    torch.cuda.synchronize()
+    assert torch.equal(plan.loss, plain.loss) and torch.equal(plan.mask, plain.mask)
+    assert torch.equal(plan.grad_T, plain.grad_T)
+    assert all(torch.equal(a, b) for a, b in zip(plan.grad_disp, plain.grad_disp))
+    for f in range(2):
+        assert float(want[f].abs().max()) > 0
+        assert _rel(got[0][f].cpu(), want[f]) <= GRAD_RTOL, f"frame {f}: {_rel(got[0][f].cpu(), want[f])}"
+        # fixed-point accumulation: independent of the order of the atomic additions
+        assert torch.equal(got[0][f], got[1][f])
+
+
+def test_color_gradient_scales_with_upstream_and_needs_the_flag():
+    from depth_estimation_amd.ops import PhotometricPlan
+    from depth_estimation_amd import _lib
+    seq = make_sequence(1, 32, 96, seed=9).to("cuda")
+    plan = PhotometricPlan(1, 32, 96, 4, "cuda", flags=_lib.DW_FLAG_COLOR_GRAD).bind(*seq.args())
+    plan.forward(True)
+    a = [c.clone() for c in plan.backward_color()]
+    b = [c.clone() for c in plan.backward_color(torch.full((1,), -3.0, device="cuda"))]
+    for x, y in zip(a, b):
+        assert _rel(x * -3.0, y) <= 1e-6
+    plain = PhotometricPlan(1, 32, 96, 4, "cuda").bind(*seq.args())
+    with pytest.raises(_lib.DepthwarpError):
+        plain.backward_color()
+    # the C entry point itself refuses a descriptor without the flag
+    rc = _lib.lib().dw_photometric_bwd_color(plain.desc, plain.one.data_ptr(), plain.ws.data_ptr(), plain.nbytes,
+                                             _lib.ptr_array(a), 0)
+    assert rc < 0

@@ -1,0 +1,20 @@
+"""Step time of the photometric stack with and without the source-image gradient (flag 4)."""
+import sys, torch
+sys.path.insert(0, ".")
+from depth_estimation_amd.ops import PhotometricPlan
+from depth_estimation_amd.synth import make_sequence
+
+B, H, W = 12, 192, 640
+seq = make_sequence(B, H, W, seed=0).to("cuda")
+for flags in (0, 4):
+    plan = PhotometricPlan(B, H, W, 4, "cuda", flags=flags).bind(*seq.args())
+    def step():
+        plan.forward(True); plan.backward()
+        if flags: plan.backward_color()
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): step()
+    e1.record(); torch.cuda.synchronize()
+    print(f"flags={flags}: {e0.elapsed_time(e1) / 50:.4f} ms/step (eager launches)")
