@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=12, help="sequences per GPU")
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--no-graph", action="store_true", help="issue launches eagerly, no HIP graph")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="replay a captured HIP graph, issue the launches eagerly, or (auto) probe both "
+                         "during warm-up and time the faster one")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="sequences in the CPU baseline sample")
     return ap.parse_args()
@@ -111,8 +114,9 @@ def main():
         step()
     torch.cuda.synchronize()
 
+    mode = "eager" if args.no_graph else args.launch
     graph = None
-    if not args.no_graph:
+    if mode != "eager":
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -121,9 +125,27 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
-        run = graph.replay
-    else:
-        run = step
+    if mode == "auto":
+        # untimed probe: a step is five launches, and which of the two ways of issuing them is
+        # faster depends on the host; every rank must take the same decision
+        def probe(fn, n=30):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        t_graph, t_eager = probe(graph.replay), probe(step)
+        if dist is not None:
+            v = torch.tensor([t_graph, t_eager], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            t_graph, t_eager = float(v[0]), float(v[1])
+        mode = "graph" if t_graph <= t_eager else "eager"
+    if mode == "eager":
+        graph = None
+    run = step if graph is None else graph.replay
 
     for _ in range(args.warmup):
         run()

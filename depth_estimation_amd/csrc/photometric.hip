@@ -11,8 +11,7 @@
 // Backward arithmetic uses explicit fmaf and fast reciprocals where it helps.
 //
 // Launch sequence of one training step:
-//   forward : disp_sum_kernel -> photo_tile_kernel<GRAD> -> smooth_kernel
-//             -> loss_finalize_kernel
+//   forward : photo_tile_kernel<GRAD> -> smooth_kernel -> loss_finalize_kernel
 //   backward: backward_kernel (pose blocks + disparity-map blocks)
 // photo_tile_kernel<true> does the whole per-pixel backward at unit upstream
 // gradient while the tile is still on chip and leaves, per scale, the gradient
@@ -101,14 +100,13 @@ struct PhotoParams {
   const float* tie;
   uint8_t* mask[DW_MAX_SCALES];
   // workspace sections
-  float* sum_part;   // [blk_off[S]]            partial sums of disp[s]
   float* tile_loss;  // [B][tiles][4]
   float* tile_dP;    // [B][tiles][S][24]
   float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
   unsigned long long* gcol;  // [2][B][3][H][W]  d loss / d (warped source image), 2^-32 fixed point; optional
   float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
-  float* sm_part;    // [blk_off[S]][3]
+  float* sm_part;    // [blk_off[S]][4]         per block: smoothness sums x, y; sum G * disp; sum disp
   ScaleLayout L;
 };
 
@@ -1104,42 +1102,17 @@ __device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, in
   chunk = r - b * L.nblk[s];
 }
 
-// ------------------------------------------------- partial sums of disp[s]
-__global__ __launch_bounds__(SM_NT) void disp_sum_kernel(const PhotoParams p) {
-  __shared__ float red[SM_NT / kWave];
-  int s, b, chunk;
-  decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
-  const long n = (long)p.L.Hs[s] * p.L.Ws[s];
-  const float* d = p.disp[s] + (long)b * n;
-  float acc = 0.f;
-  for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
-    const long i = (long)chunk * SM_PX + k;
-    if (i < n) acc += d[i];
-  }
-  const float t = block_sum<SM_NT>(acc, red);
-  if (threadIdx.x == 0) p.sum_part[blockIdx.x] = t;
-}
-
-// Mean of disp[s][b] from the per-block partial sums, fixed order; every
-// thread of the block gets the value. `red` holds SM_NT/64 + 1 floats.
-__device__ __forceinline__ float image_mean(const float* sum_part, const ScaleLayout& L, int s,
-                                            int b, float* red) {
-  const long base = (long)L.blk_off[s] + (long)b * L.nblk[s];
-  float a = 0.f;
-  for (int k = threadIdx.x; k < L.nblk[s]; k += SM_NT) a += sum_part[base + k];
-  const float t = block_sum<SM_NT>(a, red);
-  if (threadIdx.x == 0) red[SM_NT / kWave] = t / (float)((long)L.Hs[s] * L.Ws[s]);
-  __syncthreads();
-  return red[SM_NT / kWave];
-}
-
 // ------------------------------------------------- edge-aware smoothness
 // loss_s = mean_x(|d^(x) - d^(x+1)| * exp(-mean_c|I(x) - I(x+1)|)) + same in y,
-// d^ = disp / (mean + 1e-7).  Writes G = d loss_s / d d^ per pixel and per-block
-// partials (sum_x, sum_y, sum G*disp).
+// d^ = disp / (mean + 1e-7), mean = the mean of disp over the image.  The
+// normalisation is a positive factor per image, so this kernel does not need
+// it: it sums |d(x) - d(x+1)| * w on the raw disparity (the finalisation kernel
+// multiplies the sums of an image by 1 / (mean + 1e-7)), and G = d loss_s / d d^
+// depends on the differences only through their signs.  Writes G per pixel and
+// per-block partials (sum_x, sum_y, sum G*disp, sum disp): the sum of disp is
+// what the mean is made of, so no pass over disp precedes this kernel.
 template <bool GRAD>
 __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
-  __shared__ float red[SM_NT / kWave + 1];
   int s, b, chunk;
   decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
   const int hs = p.L.Hs[s], ws = p.L.Ws[s];
@@ -1148,15 +1121,13 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
   const float* I = p.pyr[s] + (long)b * 3 * n;
   const float icx = 1.0f / ((float)p.B * hs * (ws - 1));
   const float icy = 1.0f / ((float)p.B * (hs - 1) * ws);
-  float lx = 0.f, ly = 0.f, gd = 0.f;
+  float lx = 0.f, ly = 0.f, gd = 0.f, sd = 0.f;
   auto sgn = [](float a) -> float { return (a > 0.f) ? 1.f : ((a < 0.f) ? -1.f : 0.f); };
   if (p.vec4) {
     // Rows are whole float4s: a thread takes four consecutive pixels of one
     // row, reads them and their upper / lower neighbours as 16-byte vectors (a
     // missing neighbour row re-reads the centre row and is masked) and the two
     // pixels beside the group as scalars.  Same per-pixel arithmetic as below.
-    // The loads are issued before the image mean is reduced, so that the two
-    // latencies overlap (a thread past the end of the image re-reads its start).
     const long i0 = (long)chunk * SM_PX + 4 * threadIdx.x;
     const bool act = i0 < n;
     const long ia = act ? i0 : 0;
@@ -1176,12 +1147,11 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
       U[pl][0] = u.x; U[pl][1] = u.y; U[pl][2] = u.z; U[pl][3] = u.w;
       D[pl][0] = w.x; D[pl][1] = w.y; D[pl][2] = w.z; D[pl][3] = w.w;
     }
-    const float inv = 1.0f / (image_mean(p.sum_part, p.L, s, b, red) + kMeanEps);
     if (act) {
       float Gv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float dc = C[0][e + 1] * inv;
+        const float dc = C[0][e + 1];
         const float c0 = C[1][e + 1], c1 = C[2][e + 1], c2 = C[3][e + 1];
         auto edge = [&](float n0, float n1, float n2) -> float {  // exp(-mean_c |I(i) - I(j)|)
           const float m = (fabsf(c0 - n0) + fabsf(c1 - n1) + fabsf(c2 - n2)) * kThird;
@@ -1189,38 +1159,38 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
         };
         float G = 0.f;
         if (e < 3 || rt) {
-          const float a = dc - C[0][e + 2] * inv, w = edge(C[1][e + 2], C[2][e + 2], C[3][e + 2]);
+          const float a = dc - C[0][e + 2], w = edge(C[1][e + 2], C[2][e + 2], C[3][e + 2]);
           lx += fabsf(a) * w;
           G += sgn(a) * w * icx;
         }
         if (e > 0 || lf) {
-          const float a = C[0][e] * inv - dc, w = edge(C[1][e], C[2][e], C[3][e]);
+          const float a = C[0][e] - dc, w = edge(C[1][e], C[2][e], C[3][e]);
           G -= sgn(a) * w * icx;
         }
         if (dn) {
-          const float a = dc - D[0][e] * inv, w = edge(D[1][e], D[2][e], D[3][e]);
+          const float a = dc - D[0][e], w = edge(D[1][e], D[2][e], D[3][e]);
           ly += fabsf(a) * w;
           G += sgn(a) * w * icy;
         }
         if (up) {
-          const float a = U[0][e] * inv - dc, w = edge(U[1][e], U[2][e], U[3][e]);
+          const float a = U[0][e] - dc, w = edge(U[1][e], U[2][e], U[3][e]);
           G -= sgn(a) * w * icy;
         }
         Gv[e] = G;
-        if (GRAD) gd = fmaf(G, C[0][e + 1], gd);
+        sd += dc;
+        if (GRAD) gd = fmaf(G, dc, gd);
       }
       if (GRAD)
         *reinterpret_cast<float4*>(p.sm_G + p.L.pix_off[s] + (long)b * n + i0) =
             make_float4(Gv[0], Gv[1], Gv[2], Gv[3]);
     }
   } else {
-  const float inv = 1.0f / (image_mean(p.sum_part, p.L, s, b, red) + kMeanEps);
   for (int k = threadIdx.x; k < SM_PX; k += SM_NT) {
     const long i = (long)chunk * SM_PX + k;
     if (i >= n) break;
     // 32-bit index arithmetic (n < 2^30): a 64-bit division costs more than the rest of the pixel
     const int y = (int)((unsigned)i / (unsigned)ws), x = (int)((unsigned)i - (unsigned)y * (unsigned)ws);
-    const float dc = d[i] * inv;
+    const float dc = d[i];
     const float c0 = I[i], c1 = I[n + i], c2 = I[2 * n + i];
     float G = 0.f;
     auto edge = [&](long j) -> float {  // exp(-mean_c |I(i) - I(j)|)
@@ -1228,46 +1198,49 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
       return __expf(-m);
     };
     if (x + 1 < ws) {
-      const float a = dc - d[i + 1] * inv, w = edge(i + 1);
+      const float a = dc - d[i + 1], w = edge(i + 1);
       lx += fabsf(a) * w;
       G += sgn(a) * w * icx;
     }
     if (x > 0) {
-      const float a = d[i - 1] * inv - dc, w = edge(i - 1);
+      const float a = d[i - 1] - dc, w = edge(i - 1);
       G -= sgn(a) * w * icx;
     }
     if (y + 1 < hs) {
-      const float a = dc - d[i + ws] * inv, w = edge(i + ws);
+      const float a = dc - d[i + ws], w = edge(i + ws);
       ly += fabsf(a) * w;
       G += sgn(a) * w * icy;
     }
     if (y > 0) {
-      const float a = d[i - ws] * inv - dc, w = edge(i - ws);
+      const float a = d[i - ws] - dc, w = edge(i - ws);
       G -= sgn(a) * w * icy;
     }
+    sd += dc;
     if (GRAD) {
       p.sm_G[p.L.pix_off[s] + (long)b * n + i] = G;
-      gd = fmaf(G, d[i], gd);
+      gd = fmaf(G, dc, gd);
     }
   }
   }
-  // the three block sums behind one pair of barriers; thread k adds the wave values of sum k
-  __shared__ float red3[3][SM_NT / kWave];
+  // the four block sums behind one barrier; thread k adds the wave values of sum k
+  __shared__ float red4[4][SM_NT / kWave];
   lx = wave_sum(lx);
   ly = wave_sum(ly);
-  if (GRAD) gd = wave_sum(gd);
+  gd = GRAD ? wave_sum(gd) : 0.f;
+  sd = wave_sum(sd);
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   if (lane == kSumLane) {
-    red3[0][wid] = lx;
-    red3[1][wid] = ly;
-    if (GRAD) red3[2][wid] = gd;
+    red4[0][wid] = lx;
+    red4[1][wid] = ly;
+    red4[2][wid] = gd;
+    red4[3][wid] = sd;
   }
   __syncthreads();
-  if (threadIdx.x < (GRAD ? 3 : 2)) {
+  if (threadIdx.x < 4) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < SM_NT / kWave; ++i) t += red3[threadIdx.x][i];
-    p.sm_part[(long)blockIdx.x * 3 + threadIdx.x] = t;
+    for (int i = 0; i < SM_NT / kWave; ++i) t += red4[threadIdx.x][i];
+    p.sm_part[(long)blockIdx.x * 4 + threadIdx.x] = t;
   }
 }
 
@@ -1290,8 +1263,8 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
     const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
     float a0 = 0.f, a1 = 0.f;
     for (int k = lane; k < p.L.nblk[s]; k += kWave) {
-      a0 += p.sum_part[base + k];
-      a1 += p.sm_part[(base + k) * 3 + 2];
+      a0 += p.sm_part[(base + k) * 4 + 3];
+      a1 += p.sm_part[(base + k) * 4 + 2];
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
@@ -1314,22 +1287,40 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
     acc[6] += (double)v.z;
     acc[9] += (double)v.w;
   }
+  // smoothness: the sums of an image times 1 / (its mean disparity + 1e-7); one
+  // image per wave and pass, lane kSumLane of the wave keeps the running sums
+  for (int m = wid; m < p.S * p.B; m += LF_WAVES) {
+    const int s = m / p.B, b = m - s * p.B;
+    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
+    float ax = 0.f, ay = 0.f, ad = 0.f;
+    for (int k = lane; k < p.L.nblk[s]; k += kWave) {
+      const float4 v = *reinterpret_cast<const float4*>(p.sm_part + (base + k) * 4);
+      ax += v.x;
+      ay += v.y;
+      ad += v.w;
+    }
+    ax = wave_sum(ax);
+    ay = wave_sum(ay);
+    ad = wave_sum(ad);
+    const float mean = ad / (float)((long)p.L.Hs[s] * p.L.Ws[s]);
+    const double inv = (double)(1.0f / (mean + kMeanEps));
 #pragma unroll
-  for (int s = 0; s < DW_MAX_SCALES; ++s) {
-    if (s < p.S) {
-#pragma unroll 2
-      for (int k = p.L.blk_off[s] + tid; k < p.L.blk_off[s + 1]; k += 1024) {
-        acc[3 * s + 1] += (double)p.sm_part[(long)k * 3 + 0];
-        acc[3 * s + 2] += (double)p.sm_part[(long)k * 3 + 1];
-      }
+    for (int j = 0; j < DW_MAX_SCALES; ++j) {
+      acc[3 * j + 1] += (s == j) ? inv * (double)ax : 0.0;
+      acc[3 * j + 2] += (s == j) ? inv * (double)ay : 0.0;
     }
   }
+  // (only lane kSumLane holds wave sums: the other lanes' smoothness sums are discarded below)
 #pragma unroll
   for (int k = 0; k < 3 * DW_MAX_SCALES; ++k) {
-    double a = acc[k];
+    if (k % 3 == 0) {  // tile losses: every lane has a partial sum
+      double a = acc[k];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
-    if (lane == 0) s_part[k][wid] = a;
+      for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+      if (lane == 0) s_part[k][wid] = a;
+    } else if (lane == kSumLane) {
+      s_part[k][wid] = acc[k];
+    }
   }
   __syncthreads();
   if (tid < 3 * DW_MAX_SCALES) {  // thread k finishes sum k
@@ -1360,7 +1351,6 @@ struct BwdParams {
   const float* disp[DW_MAX_SCALES];
   const float* K;
   const float* grad_loss;
-  const float* sum_part;
   const float* tile_dP;
   const float* gdup;
   const float* img_scal;
@@ -1505,7 +1495,7 @@ __global__ __launch_bounds__(SM_NT) void grad_color_kernel(const long long* __re
 
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t sum_part, tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, gcol, total;
+  size_t tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, gcol, total;
 };
 
 struct TileCounts {
@@ -1536,14 +1526,12 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   }
   const size_t A = 256;
   size_t o = 0;
-  w.sum_part = o;
-  o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S], A);
   w.tile_loss = o;
   o = align_up(o + sizeof(float) * (size_t)d.B * tiles_max * DW_MAX_SCALES, A);
   w.tile_dP = o;
   o = align_up(o + sizeof(float) * (size_t)d.B * tiles_g * DW_MAX_SCALES * 24, A);
   w.sm_part = o;
-  o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S] * 3, A);
+  o = align_up(o + sizeof(float) * (size_t)L.blk_off[d.S] * 4, A);
   w.sm_G = o;
   o = align_up(o + sizeof(float) * (size_t)L.pix_off[d.S], A);
   w.img_scal = o;
@@ -1644,7 +1632,6 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.T = T;
   p.tie = tie_noise;
   char* ws = (char*)workspace;
-  p.sum_part = (float*)(ws + w.sum_part);
   p.tile_loss = (float*)(ws + w.tile_loss);
   p.tile_dP = (float*)(ws + w.tile_dP);
   p.gdup = (float*)(ws + w.gdup);
@@ -1670,7 +1657,6 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
       photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
     return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
   }
-  disp_sum_kernel<<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   if (with_grad) {
     if (cgrad)
       photo_tile_color_kernel<<<tgrid, Geom<true>::NT, 0, st>>>(p);
@@ -1713,7 +1699,6 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   p.K = K;
   p.grad_loss = grad_loss;
   const char* ws = (const char*)workspace;
-  p.sum_part = (const float*)(ws + w.sum_part);
   p.tile_dP = (const float*)(ws + w.tile_dP);
   p.gdup = (const float*)(ws + w.gdup);
   p.img_scal = (const float*)(ws + w.img_scal);
