@@ -66,7 +66,7 @@ def cpu_baseline(args):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if n >= 3 and (el > 10.0 or n >= 10):
+        if n >= 3 and el > 10.0:  # about ten seconds of CPU work
             break
         if el > 25.0:
             break
