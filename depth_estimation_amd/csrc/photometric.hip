@@ -571,7 +571,9 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       }
       // keep the scheduler from interleaving the bodies: that would hold every
       // window of the strip in registers at once
+#ifndef DW_B_NOBARRIER
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -909,14 +911,41 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int j = 0; j < WW; ++j) w0[r][j] = (nsel[r][j] == 0) ? wy[r] : 0.f;
+#ifndef DW_C_PREFETCH
+#define DW_C_PREFETCH 1
+#endif
+#if DW_C_PREFETCH
+        // the coefficient planes of the next channel are read while the current one is summed
+        float gbuf[2][3][3][WW];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) loadw(&s_un[k3 * GN + gwin + r * RP], gbuf[0][k3][r]);
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int c = 0; c < 3; ++c) {
           float tot[SW][3], af0[SW][3];
+#if DW_C_PREFETCH
+          if (c + 1 < 3) {
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+              for (int r = 0; r < 3; ++r)
+                loadw(&s_un[(3 * (c + 1) + k3) * GN + gwin + r * RP], gbuf[(c + 1) & 1][k3][r]);
+          }
+#endif
 #pragma unroll
           for (int k3 = 0; k3 < 3; ++k3) {
-            float g[3][WW], cs[WW], cs0[WW];
+            float cs[WW], cs0[WW];
+#if DW_C_PREFETCH
+            const float (*g)[WW] = gbuf[c & 1][k3];
+#else
+            float g[3][WW];
 #pragma unroll
             for (int r = 0; r < 3; ++r) loadw(&s_un[(3 * c + k3) * GN + gwin + r * RP], g[r]);
+#endif
 #pragma unroll
             for (int j = 0; j < WW; ++j) {
               cs[j] = fmaf(wy[0], g[0][j], fmaf(wy[2], g[2][j], g[1][j]));
@@ -959,7 +988,9 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
               }
             }
           }
+#ifndef DW_C_NOBARRIER
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         // Branch-free: a pixel without a contribution runs the same arithmetic on
         // zeros (its depth, its gradient and the reciprocal are zeroed), which adds
