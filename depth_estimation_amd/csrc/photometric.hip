@@ -419,6 +419,14 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
     float tapv[NIT][DW_MAX_SCALES][4];
     float wy0[NIT][DW_MAX_SCALES], wy1[NIT][DW_MAX_SCALES], wx0[NIT][DW_MAX_SCALES], wx1[NIT][DW_MAX_SCALES];
     int lis[NIT];
+    // low-resolution size / full-resolution size of every scale, once (uniform values)
+    float rsy[DW_MAX_SCALES], rsx[DW_MAX_SCALES];
+#pragma unroll
+    for (int s = 0; s < DW_MAX_SCALES; ++s) {
+      const int sc = (s >= s_lo && s < s_hi) ? s : s_lo;
+      rsy[s] = uniform((float)(H >> sc) / (float)H);
+      rsx[s] = uniform((float)(W >> sc) / (float)W);
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int i = tid + it * NT;
@@ -445,8 +453,8 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
           wy0[it][s] = wx0[it][s] = 1.f;
           wy1[it][s] = wx1[it][s] = 0.f;
         } else {
-          const Taps ty = upsample_taps(y, hs, (float)hs / (float)H);
-          const Taps tx = upsample_taps(x, ws, (float)ws / (float)W);
+          const Taps ty = upsample_taps(y, hs, rsy[s]);
+          const Taps tx = upsample_taps(x, ws, rsx[s]);
           tapv[it][s][0] = tap(d, (unsigned)(ty.i0 * ws + tx.i0) * 4u);
           tapv[it][s][1] = tap(d, (unsigned)(ty.i0 * ws + tx.i1) * 4u);
           tapv[it][s][2] = tap(d, (unsigned)(ty.i1 * ws + tx.i0) * 4u);
