@@ -166,6 +166,11 @@ struct Sample {
 // where to sample, the twelve taps, the blend.
 struct SampleAddr {
   unsigned o_nw, o_ne, o_sw, o_se;  // byte offsets of the four taps inside a colour plane
+  // The two taps of a row are neighbours in memory, so the gather reads them as
+  // one 8-byte pair starting at column min(x0, W - 2): o_n / o_s are the byte
+  // offsets of the upper / lower pair, and `hi` says that the left tap is the
+  // second element of its pair (x0 = W - 1, where both taps are that column).
+  unsigned o_n, o_s, hi;
   float tx, ty;                     // fractional position inside the cell
   // status bits of the sample, already at their place in the region's status byte
   // for source frame f: bit 2 + f inside the image before clamping and in front of
@@ -174,9 +179,14 @@ struct SampleAddr {
   // boolean that lives across other work costs a pair of scalar registers.
   unsigned vb;
 };
+typedef float PairU __attribute__((ext_vector_type(2), aligned(4)));  // 8 bytes, dword aligned
 struct SampleTaps {
-  float nw[3], ne[3], sw[3], se[3];
+  PairU n[3], s[3];  // upper and lower pair of every channel
 };
+// An 8-byte load from a base pointer plus a 32-bit per-lane byte offset (dword aligned).
+__device__ __forceinline__ PairU tap2(GlobalFloats base, unsigned byte_off) {
+  return *(const __attribute__((address_space(1))) PairU*)((GlobalBytes)base + byte_off);
+}
 
 // Project the camera-space point (X,Y,Z) with P (3x4, row-major); border
 // padding, corners aligned.
@@ -211,6 +221,10 @@ __device__ __forceinline__ void sample_addr(int H, int W, const float* P, float 
   a.o_ne = (unsigned)(y0 * W + x1) * 4u;
   a.o_sw = (unsigned)(y1 * W + x0) * 4u;
   a.o_se = (unsigned)(y1 * W + x1) * 4u;
+  const int xb = min(x0, W - 2);
+  a.o_n = (unsigned)(y0 * W + xb) * 4u;
+  a.o_s = (unsigned)(y1 * W + xb) * 4u;
+  a.hi = (unsigned)(x0 - xb);
 }
 
 // uniform plane base + 32-bit per-lane offset: no 64-bit address arithmetic per tap
@@ -219,10 +233,8 @@ __device__ __forceinline__ void sample_gather(GlobalFloats src, long plane,
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const GlobalFloats p = src + c * plane;
-    t.nw[c] = tap(p, a.o_nw);
-    t.ne[c] = tap(p, a.o_ne);
-    t.sw[c] = tap(p, a.o_sw);
-    t.se[c] = tap(p, a.o_se);
+    t.n[c] = tap2(p, a.o_n);
+    t.s[c] = tap2(p, a.o_s);
   }
 }
 
@@ -233,7 +245,8 @@ __device__ __forceinline__ void sample_blend(const SampleAddr& a, const SampleTa
   const float w_nw = ex * ey, w_ne = tx * ey, w_sw = ex * ty, w_se = tx * ty;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float nw = t.nw[c], ne = t.ne[c], sw = t.sw[c], se = t.se[c];
+    const float ne = t.n[c].y, se = t.s[c].y;
+    const float nw = a.hi ? ne : t.n[c].x, sw = a.hi ? se : t.s[c].x;
     o.val[c] = ((nw * w_nw + ne * w_ne) + sw * w_sw) + se * w_se;
     if (WITH_GRAD) {
       o.dx[c] = fmaf(se - sw, ty, (ne - nw) * ey);
