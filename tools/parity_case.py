@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""One case of parity_sweep.py in detail: python tools/parity_case.py SEED B H W"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from depth_estimation_amd import ops
+from depth_estimation_amd.synth import make_sequence
+from oracle import photometric as ph
+seed, B, H, W = (int(v) for v in sys.argv[1:5])
+seq = make_sequence(B, H, W, seed=1000 + seed, tie_noise=(seed % 3 == 0))
+if seed % 2:
+    T = seq.T.clone(); g = torch.Generator().manual_seed(seed)
+    T[:, :, :3, 3] += torch.randn(B, 2, 3, generator=g) * (0.5 * seed); seq.T = T
+disp = [d.clone().requires_grad_(True) for d in seq.disp]
+T = seq.T.clone().requires_grad_(True)
+loss = ph.photometric_stack(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T, seq.tie_noise)
+loss.backward()
+gq = seq.to("cuda")
+hd = [d.clone().requires_grad_(True) for d in gq.disp]
+hT = gq.T.clone().requires_grad_(True)
+terms, mask = ops.photometric_forward(hd, gq.color, gq.color_pyr, gq.K, gq.inv_K, hT, gq.tie_noise)
+terms[0].backward()
+# smoothness-only gradient of the oracle, to tell the two parts apart
+d2 = [d.detach().clone().requires_grad_(True) for d in seq.disp]
+sm = sum(1e-3 * ph.smooth_loss(d2[s], seq.color_pyr[s]) / 2 ** s for s in range(4)) / 4
+sm.backward()
+for s in range(4):
+    a, b = hd[s].grad.cpu(), disp[s].grad
+    e = (a - b).abs()
+    i = int(e.argmax()); hw = b.shape[-1]
+    y, x = (i % (b.shape[-2] * hw)) // hw, i % hw
+    print(f"scale {s}: rel {float(e.max() / b.abs().max()):.2e} at (y={y}, x={x}) hip {float(a.flatten()[i]):.6e} "
+          f"oracle {float(b.flatten()[i]):.6e} max|g| {float(b.abs().max()):.3e} smooth part {float(d2[s].grad.flatten()[i]):.3e}")
+    dd = seq.disp[s][0, 0]
+    if 0 < x < hw - 1 and 0 < y < dd.shape[0] - 1:
+        print("   neighbour differences", [float(dd[y, x] - dd[y, x + 1]), float(dd[y, x - 1] - dd[y, x]),
+                                           float(dd[y, x] - dd[y + 1, x]), float(dd[y - 1, x] - dd[y, x])])
