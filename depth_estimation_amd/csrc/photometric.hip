@@ -156,6 +156,31 @@ __device__ __forceinline__ GlobalFloats uniform_ptr(const float* ptr) {
   return (GlobalFloats)(((unsigned long long)hi << 32) | lo);
 }
 
+// IEEE division in fewer instructions.  hipcc expands n / d into: scale both
+// operands if the quotient could leave the normal range (v_div_scale), y =
+// reciprocal of d refined once, q = n * y corrected twice with the exact
+// residual, undo the scaling (v_div_fmas), special cases (v_div_fixup).  When
+// no scaling happens -- d normal, exponents of n and d less than 96 apart, n
+// not below 2^-103 -- the two scale instructions are copies and v_div_fmas is a
+// plain fma, so the sequence below returns the same bits with y computed once
+// per divisor instead of once per division.  Every use in this file divides
+// quantities inside that range (projected coordinates by a depth or by an image
+// size, the SSIM numerator by its denominator); tools/micro/div_exact.hip checks
+// the sequence against `/` over all 2^32 numerators for a set of image sizes
+// and over 2^32 random pairs of each use.
+__device__ __forceinline__ float div_rcp(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float div_by(float n, float d, float y) {
+  float q = n * y;
+  float e = fmaf(-d, q, n);
+  q = fmaf(e, y, q);
+  e = fmaf(-d, q, n);
+  q = fmaf(e, y, q);
+  return __builtin_amdgcn_div_fixupf(q, d, n);
+}
+
 struct Sample {
   float val[3];
   float dx[3], dy[3];  // d val[c] / d (sample x, y) in pixels, before the border mask
@@ -190,18 +215,23 @@ __device__ __forceinline__ PairU tap2(GlobalFloats base, unsigned byte_off) {
 
 // Project the camera-space point (X,Y,Z) with P (3x4, row-major); border
 // padding, corners aligned.
+// refined reciprocals of W - 1 and H - 1 (uniform, computed once per block)
+struct DivConsts {
+  float yw, yh;
+};
 template <bool WITH_GRAD>
-__device__ __forceinline__ void sample_addr(int H, int W, const float* P, float X, float Y, float Z,
-                                            unsigned f, SampleAddr& a) {
+__device__ __forceinline__ void sample_addr(int H, int W, const DivConsts& dc, const float* P, float X, float Y,
+                                            float Z, unsigned f, SampleAddr& a) {
   const float c0 = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3];
   const float c1 = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7];
   const float c2 = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11];
   const float zp = c2 + kProjEps;
-  const float u = c0 / zp;
-  const float v = c1 / zp;
+  const float yz = div_rcp(zp);
+  const float u = div_by(c0, zp, yz);  // c0 / zp
+  const float v = div_by(c1, zp, yz);  // c1 / zp
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-  const float gx = (u / wm1 - 0.5f) * 2.0f;
-  const float gy = (v / hm1 - 0.5f) * 2.0f;
+  const float gx = (div_by(u, wm1, dc.yw) - 0.5f) * 2.0f;  // u / (W - 1)
+  const float gy = (div_by(v, hm1, dc.yh) - 0.5f) * 2.0f;  // v / (H - 1)
   const bool valid = (gx >= -1.f) && (gx <= 1.f) && (gy >= -1.f) && (gy <= 1.f) && (c2 > 0.f);
   a.vb = valid ? (4u << f) : 0u;
   float ix = ((gx + 1.0f) * 0.5f) * wm1;
@@ -297,7 +327,7 @@ __device__ __forceinline__ float ssim_loss_px(float mux, float muy, float exx, f
   t.B2 = (sx + sy) + kC2;
   const float n = t.A1 * t.A2;
   const float d = t.B1 * t.B2;
-  t.r = n / d;
+  t.r = div_by(n, d, div_rcp(d));
   t.raw = (1.0f - t.r) * 0.5f;
   return fminf(fmaxf(t.raw, 0.f), 1.f);
 }
@@ -520,6 +550,9 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) iK[k] = uniform(s_invK[k]);
+  DivConsts dc;
+  dc.yw = uniform(div_rcp((float)(W - 1)));
+  dc.yh = uniform(div_rcp((float)(H - 1)));
 
   // image coordinates and status of the pixels of this thread's strip
   const int sy_img = qy0 + qr;
@@ -665,10 +698,10 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
       // both frames' taps are in flight before the first blend: frame 1 is
       // projected while the loads of frame 0 travel
-      sample_addr<GRAD>(H, W, P0, X, Y, Z, 0u, qa[0]);
+      sample_addr<GRAD>(H, W, dc, P0, X, Y, Z, 0u, qa[0]);
       sample_gather(src_b[0], plane, qa[0], qt[0]);
       __builtin_amdgcn_sched_barrier(0);
-      sample_addr<GRAD>(H, W, P1, X, Y, Z, 1u, qa[1]);
+      sample_addr<GRAD>(H, W, dc, P1, X, Y, Z, 1u, qa[1]);
       sample_gather(src_b[1], plane, qa[1], qt[1]);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -721,7 +754,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
 #pragma unroll
       for (int k = 0; k < 12; ++k) Pf[k] = q.f ? P1[k] : P0[k];
       const GlobalFloats srcf = q.f ? src_b[1] : src_b[0];
-      sample_addr<GRAD>(H, W, Pf, X, Y, Z, (unsigned)q.f, qa);
+      sample_addr<GRAD>(H, W, dc, Pf, X, Y, Z, (unsigned)q.f, qa);
       sample_gather(srcf, plane, qa, qt);
     };
     auto finish_left = [&](const Px& q, const SampleAddr& qa, const SampleTaps& qt) __attribute__((always_inline)) {
@@ -923,7 +956,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int q = 0; q < SW; ++q)
-              sample_addr<false>(H, W, f ? P1 : P0, depth[q] * r0[q], depth[q] * r1[q], depth[q] * r2[q],
+              sample_addr<false>(H, W, dc, f ? P1 : P0, depth[q] * r0[q], depth[q] * r1[q], depth[q] * r2[q],
                                  (unsigned)f, ca[CGRAD ? f : 0][q]);
         }
         // weights of the frame-0 neighbours (row weight times mask), shared by the nine planes
