@@ -48,6 +48,20 @@ def photo_case(c):
     return out
 
 
+COLOR_CASES = [dict(B=1, H=32, W=96, seed=9)]
+
+
+def color_case(c):
+    """Gradient of the loss w.r.t. the two source images as the warp samples them."""
+    seq = make_sequence(c["B"], c["H"], c["W"], seed=c["seed"])
+    warp_src = [seq.color[1 + f].clone().requires_grad_(True) for f in range(2)]
+    loss = ph.photometric_stack(seq.disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, seq.T,
+                                warp_src=warp_src)
+    loss.backward()
+    return {"loss": loss.detach().numpy(), "grad_color0": warp_src[0].grad.numpy(),
+            "grad_color1": warp_src[1].grad.numpy()}
+
+
 def cl_inputs(c):
     g = torch.Generator().manual_seed(c["seed"])
     target = torch.rand(c["B"], c["Ht"], c["Wt"], generator=g)
@@ -59,6 +73,10 @@ def main():
     for c in PHOTO_CASES:
         name = f"photo_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}{'_tie' if c['tie'] else ''}.npz"
         np.savez_compressed(os.path.join(HERE, name), **photo_case(c))
+        print("wrote", name)
+    for c in COLOR_CASES:
+        name = f"colorgrad_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}.npz"
+        np.savez_compressed(os.path.join(HERE, name), **color_case(c))
         print("wrote", name)
     rows = {}
     for i, c in enumerate(CL_CASES):

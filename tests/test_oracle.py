@@ -184,3 +184,14 @@ def test_compute_loss_oracle_closed_forms_and_golden():
     tgt, pred = cl_inputs(CL_CASES[0])
     out = cl.compute_loss(tgt.double(), pred)
     assert out.dim() == 0 and not out.requires_grad
+
+
+def test_oracle_reproduces_color_gradient_golden():
+    from tests.golden.make_golden import COLOR_CASES, color_case
+    for c in COLOR_CASES:
+        gold = np.load(os.path.join(GOLDEN, f"colorgrad_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}.npz"))
+        got = color_case(c)
+        assert abs(float(got["loss"]) - float(gold["loss"])) <= 1e-6 * abs(float(gold["loss"]))
+        for f in range(2):
+            assert np.allclose(got[f"grad_color{f}"], gold[f"grad_color{f}"], rtol=1e-4, atol=1e-10)
+            assert np.abs(gold[f"grad_color{f}"]).max() > 0

@@ -274,3 +274,20 @@ def test_color_gradient_scales_with_upstream_and_needs_the_flag():
     rc = _lib.lib().dw_photometric_bwd_color(plain.desc, plain.one.data_ptr(), plain.ws.data_ptr(), plain.nbytes,
                                              _lib.ptr_array(a), 0)
     assert rc < 0
+
+
+def test_color_gradient_matches_committed_golden_vectors():
+    import os
+    import numpy as np
+    from depth_estimation_amd.ops import PhotometricPlan
+    from depth_estimation_amd._lib import DW_FLAG_COLOR_GRAD
+    from tests.golden.make_golden import COLOR_CASES
+    for c in COLOR_CASES:
+        gold = np.load(os.path.join(os.path.dirname(__file__), "golden",
+                                    f"colorgrad_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}.npz"))
+        seq = make_sequence(c["B"], c["H"], c["W"], seed=c["seed"]).to("cuda")
+        plan = PhotometricPlan(c["B"], c["H"], c["W"], 4, "cuda", flags=DW_FLAG_COLOR_GRAD).bind(*seq.args())
+        plan.forward(True)
+        got = plan.backward_color()
+        for f in range(2):
+            assert _rel(got[f].cpu(), torch.from_numpy(gold[f"grad_color{f}"])) <= GRAD_RTOL
