@@ -193,10 +193,11 @@ struct SampleAddr {
   unsigned o_nw, o_ne, o_sw, o_se;  // byte offsets of the four taps inside a colour plane
   // The two taps of a row are neighbours in memory, so the gather reads them as
   // one 8-byte pair starting at column min(x0, W - 2): o_n / o_s are the byte
-  // offsets of the upper / lower pair, and `hi` says that the left tap is the
-  // second element of its pair (x0 = W - 1, where both taps are that column).
-  unsigned o_n, o_s, hi;
-  float tx, ty;                     // fractional position inside the cell
+  // offsets of the upper / lower pair.  At x0 = W - 1 both taps are the second
+  // element of the pair and the fraction is 0; the blend then runs with tx = 1,
+  // which gives the first element weight 0 and the same sums (x * 0 + y = y).
+  unsigned o_n, o_s;
+  float tx, ty;                     // fractional position inside the pair / cell
   // status bits of the sample, already at their place in the region's status byte
   // for source frame f: bit 2 + f inside the image before clamping and in front of
   // the camera; bits 6f, 6f + 1 strictly inside the image in x, y (the clamp is
@@ -243,7 +244,6 @@ __device__ __forceinline__ void sample_addr(int H, int W, const DivConsts& dc, c
   ix = fminf(fmaxf(ix, 0.f), wm1);
   iy = fminf(fmaxf(iy, 0.f), hm1);
   const float ix0 = floorf(ix), iy0 = floorf(iy);
-  a.tx = ix - ix0;
   a.ty = iy - iy0;
   const int x0 = (int)ix0, y0 = (int)iy0;
   const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
@@ -254,7 +254,7 @@ __device__ __forceinline__ void sample_addr(int H, int W, const DivConsts& dc, c
   const int xb = min(x0, W - 2);
   a.o_n = (unsigned)(y0 * W + xb) * 4u;
   a.o_s = (unsigned)(y1 * W + xb) * 4u;
-  a.hi = (unsigned)(x0 - xb);
+  a.tx = (x0 > xb) ? 1.0f : ix - ix0;
 }
 
 // uniform plane base + 32-bit per-lane offset: no 64-bit address arithmetic per tap
@@ -275,8 +275,7 @@ __device__ __forceinline__ void sample_blend(const SampleAddr& a, const SampleTa
   const float w_nw = ex * ey, w_ne = tx * ey, w_sw = ex * ty, w_se = tx * ty;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float ne = t.n[c].y, se = t.s[c].y;
-    const float nw = a.hi ? ne : t.n[c].x, sw = a.hi ? se : t.s[c].x;
+    const float nw = t.n[c].x, ne = t.n[c].y, sw = t.s[c].x, se = t.s[c].y;
     o.val[c] = ((nw * w_nw + ne * w_ne) + sw * w_sw) + se * w_se;
     if (WITH_GRAD) {
       o.dx[c] = fmaf(se - sw, ty, (ne - nw) * ey);
@@ -614,13 +613,10 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         if (GRAD && want_g) {
           // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2, 1/d; zero where the clamp is active
           const bool open = (t.raw >= 0.f) && (t.raw <= 1.f);
-          const float up = (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2);
-          const float g0 = up * (2.0f * muy[c][q] * (t.A2 - t.A1) - t.r * 2.0f * mux * (t.B2 - t.B1));
-          const float g1 = up * (-t.r * t.B1);
-          const float g2 = up * (2.0f * t.A1);
-          Gc[f][q][3 * c + 0] = open ? g0 : 0.f;
-          Gc[f][q][3 * c + 1] = open ? g1 : 0.f;
-          Gc[f][q][3 * c + 2] = open ? g2 : 0.f;
+          const float up = open ? (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2) : 0.f;
+          Gc[f][q][3 * c + 0] = up * (2.0f * muy[c][q] * (t.A2 - t.A1) - t.r * 2.0f * mux * (t.B2 - t.B1));
+          Gc[f][q][3 * c + 1] = up * (-t.r * t.B1);
+          Gc[f][q][3 * c + 2] = up * (2.0f * t.A1);
         }
       }
       // keep the scheduler from interleaving the bodies: that would hold every
