@@ -231,18 +231,23 @@ __device__ __forceinline__ void sample_addr(int H, int W, const DivConsts& dc, c
   const float u = div_by(c0, zp, yz);  // c0 / zp
   const float v = div_by(c1, zp, yz);  // c1 / zp
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-  const float gx = (div_by(u, wm1, dc.yw) - 0.5f) * 2.0f;  // u / (W - 1)
-  const float gy = (div_by(v, hm1, dc.yh) - 0.5f) * 2.0f;  // v / (H - 1)
-  const bool valid = (gx >= -1.f) && (gx <= 1.f) && (gy >= -1.f) && (gy <= 1.f) && (c2 > 0.f);
+  // The formulation normalises to gx = (u / (W - 1) - 0.5) * 2, tests gx in [-1, 1] and
+  // samples at ix = ((gx + 1) * 0.5) * (W - 1).  Scaling by 2 and by 0.5 is exact in binary
+  // floating point, so with hx = u / (W - 1) - 0.5: gx in [-1, 1] <=> |hx| <= 0.5 and
+  // (gx + 1) * 0.5 = hx + 0.5, bit for bit (an overflow of 2 * hx only meets clamped samples).
+  const float hx = div_by(u, wm1, dc.yw) - 0.5f;  // u / (W - 1) - 0.5
+  const float hy = div_by(v, hm1, dc.yh) - 0.5f;  // v / (H - 1) - 0.5
+  const bool valid = (fabsf(hx) <= 0.5f) && (fabsf(hy) <= 0.5f) && (c2 > 0.f);
   a.vb = valid ? (4u << f) : 0u;
-  float ix = ((gx + 1.0f) * 0.5f) * wm1;
-  float iy = ((gy + 1.0f) * 0.5f) * hm1;
+  float ix = (hx + 0.5f) * wm1;
+  float iy = (hy + 0.5f) * hm1;
   if (WITH_GRAD) {
     a.vb |= ((ix > 0.f) && (ix < wm1)) ? (1u << (6u * f)) : 0u;
     a.vb |= ((iy > 0.f) && (iy < hm1)) ? (2u << (6u * f)) : 0u;
   }
-  ix = fminf(fmaxf(ix, 0.f), wm1);
-  iy = fminf(fmaxf(iy, 0.f), hm1);
+  // median of (ix, 0, W - 1) = min(max(ix, 0), W - 1), one instruction (a NaN gives 0 either way)
+  ix = __builtin_amdgcn_fmed3f(ix, 0.f, wm1);
+  iy = __builtin_amdgcn_fmed3f(iy, 0.f, hm1);
   const float ix0 = floorf(ix), iy0 = floorf(iy);
   a.ty = iy - iy0;
   const int x0 = (int)ix0, y0 = (int)iy0;
@@ -328,7 +333,7 @@ __device__ __forceinline__ float ssim_loss_px(float mux, float muy, float exx, f
   const float d = t.B1 * t.B2;
   t.r = div_by(n, d, div_rcp(d));
   t.raw = (1.0f - t.r) * 0.5f;
-  return fminf(fmaxf(t.raw, 0.f), 1.f);
+  return __builtin_amdgcn_fmed3f(t.raw, 0.f, 1.f);  // clamp to [0, 1]
 }
 
 // 3x3 window sums of one strip: column sums (top + mid) + bot for the six
