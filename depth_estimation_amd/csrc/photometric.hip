@@ -322,11 +322,14 @@ struct SsimTerms {
 
 __device__ __forceinline__ float ssim_loss_px(float mux, float muy, float exx, float eyy,
                                               float exy, SsimTerms& t) {
+  const float pxy = mux * muy;
   const float sx = exx - mux * mux;
   const float sy = eyy - muy * muy;
-  const float sxy = exy - mux * muy;
-  t.A1 = (2.0f * mux) * muy + kC1;
-  t.A2 = 2.0f * sxy + kC2;
+  const float sxy = exy - pxy;
+  // (2 * mux) * muy + C1 and 2 * sxy + C2: doubling is exact, so one fused
+  // multiply-add by 2 rounds once, like the addition it replaces
+  t.A1 = fmaf(2.0f, pxy, kC1);
+  t.A2 = fmaf(2.0f, sxy, kC2);
   t.B1 = (mux * mux + muy * muy) + kC1;
   t.B2 = (sx + sy) + kC2;
   const float n = t.A1 * t.A2;
@@ -619,9 +622,10 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
           // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2, 1/d; zero where the clamp is active
           const bool open = (t.raw >= 0.f) && (t.raw <= 1.f);
           const float up = open ? (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2) : 0.f;
-          Gc[f][q][3 * c + 0] = up * (2.0f * muy[c][q] * (t.A2 - t.A1) - t.r * 2.0f * mux * (t.B2 - t.B1));
+          const float up2 = up + up;
+          Gc[f][q][3 * c + 0] = up2 * fmaf(-(t.r * mux), t.B2 - t.B1, muy[c][q] * (t.A2 - t.A1));
           Gc[f][q][3 * c + 1] = up * (-t.r * t.B1);
-          Gc[f][q][3 * c + 2] = up * (2.0f * t.A1);
+          Gc[f][q][3 * c + 2] = up2 * t.A1;
         }
       }
       // keep the scheduler from interleaving the bodies: that would hold every
