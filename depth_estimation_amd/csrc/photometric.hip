@@ -621,10 +621,11 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         if (GRAD && want_g) {
           // upstream: 0.85/3 from the channel mean, -1/2 from (1 - r)/2, 1/d; zero where the clamp is active
           const bool open = (t.raw >= 0.f) && (t.raw <= 1.f);
-          const float up = open ? (-0.5f * kWSsim * kThird) * __builtin_amdgcn_rcpf(t.B1 * t.B2) : 0.f;
-          const float up2 = up + up;
+          // the 1/9 of the window mean is part of the constant, and the plane of the x * x
+          // term carries the 2 of d(x * x): stage C then needs two fused multiply-adds per value
+          const float up2 = open ? (-kWSsim * kThird * kNinth) * __builtin_amdgcn_rcpf(t.B1 * t.B2) : 0.f;
           Gc[f][q][3 * c + 0] = up2 * fmaf(-(t.r * mux), t.B2 - t.B1, muy[c][q] * (t.A2 - t.A1));
-          Gc[f][q][3 * c + 1] = up * (-t.r * t.B1);
+          Gc[f][q][3 * c + 1] = up2 * (-t.r * t.B1);
           Gc[f][q][3 * c + 2] = up2 * t.A1;
         }
       }
@@ -890,6 +891,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         }
         // winning frame of the 3 x WW neighbourhood (Q rows qr-1..qr+1, cols SW*ql-1..SW*ql+SW)
         int nsel[3][WW];
+        unsigned wrow[3];
         const int gwin = (qr - 1) * RP + SW * ql;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -910,19 +912,32 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
           }
 #pragma unroll
           for (int j = 0; j < WW; ++j) nsel[r][j] = (int)((w[j >> 2] >> (8 * (j & 3) + 4)) & 3) - 1;
+          wrow[r] = w[0];
         }
+        // Bits 4 and 5 of a status byte are one-hot (frame 0 / frame 1 won), so for
+        // two-pixel strips, whose neighbourhood row is one 32-bit word, "did frame f
+        // win anywhere in the 3 x 3 window of pixel q" is a mask test on the OR of
+        // the three row words.
         bool any[2][SW];
+        if (SW == 2) {
+          const unsigned m_or = wrow[0] | wrow[1] | wrow[2];
+          any[0][0] = (m_or & 0x00101010u) != 0;
+          any[0][SW - 1] = (m_or & 0x10101000u) != 0;
+          any[1][0] = (m_or & 0x00202020u) != 0;
+          any[1][SW - 1] = (m_or & 0x20202000u) != 0;
+        } else {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+          for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int q = 0; q < SW; ++q) {
-            bool a = false;
+            for (int q = 0; q < SW; ++q) {
+              bool a = false;
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+              for (int r = 0; r < 3; ++r)
 #pragma unroll
-              for (int j = 0; j < 3; ++j) a = a || (nsel[r][q + j] == f);
-            any[f][q] = a;
-          }
+                for (int j = 0; j < 3; ++j) a = a || (nsel[r][q + j] == f);
+              any[f][q] = a;
+            }
+        }
         // per-pixel geometry shared by both frames
         float depth[SW], r0[SW], r1[SW], r2[SW];
         bool live[SW];
@@ -969,7 +984,15 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int j = 0; j < WW; ++j) w0[r][j] = (nsel[r][j] == 0) ? wy[r] : 0.f;
+          for (int j = 0; j < WW; ++j) {
+            if (SW == 2) {
+              // bit 4 of byte j as 0.0 / 1.0 (a byte-to-float conversion), times the row weight
+              const unsigned won0 = (wrow[r] >> 4) & 0x01010101u;
+              w0[r][j] = (float)((won0 >> (8 * j)) & 0xffu) * wy[r];
+            } else {
+              w0[r][j] = (nsel[r][j] == 0) ? wy[r] : 0.f;
+            }
+          }
 #ifndef DW_C_PREFETCH
 #define DW_C_PREFETCH 1
 #endif
@@ -1026,7 +1049,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
               const float a1 = f ? tot[q][1] - af0[q][1] : af0[q][1];
               const float a2 = f ? tot[q][2] - af0[q][2] : af0[q][2];
               const float xq = st[c * QH * QW];
-              float gx = kNinth * (a0 + 2.0f * xq * a1 + yq * a2);
+              float gx = fmaf(xq, a1, fmaf(yq, a2, a0));
               if (sel[q] == f) {
                 const float df = xq - yq;
                 gx += kWL1 * kThird * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
