@@ -113,8 +113,8 @@ __device__ __forceinline__ float buf_load_f32(buf_rsrc r, unsigned lane_off, uns
 }
 
 __device__ __forceinline__ int reflect_index(int i, int n) {
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * (n - 1) - i;
+  i = abs(i);
+  i = min(i, 2 * (n - 1) - i);  // reflected at n - 1 when beyond it
   return min(max(i, 0), n - 1);
 }
 

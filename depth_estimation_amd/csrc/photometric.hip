@@ -695,7 +695,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
       q.li = ry * RP + rx;
-      q.stash = ry >= 1 && ry <= QH && rx >= 1 && rx <= QW;
+      q.stash = (unsigned)(ry - 1) < (unsigned)QH && (unsigned)(rx - 1) < (unsigned)QW;
       q.sti = (ry - 1) * QW + (rx - 1);
       const float depth = s_depth[s * RN + q.li];
       const float fx = (float)x, fy = (float)y;
@@ -749,7 +749,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
       q.li = ry * RP + rx;
-      q.stash = ry >= 1 && ry <= QH && rx >= 1 && rx <= QW;
+      q.stash = (unsigned)(ry - 1) < (unsigned)QH && (unsigned)(rx - 1) < (unsigned)QW;
       q.sti = (ry - 1) * QW + (rx - 1);
       const float depth = s_depth[s * RN + q.li];
       const float fx = (float)x, fy = (float)y;
@@ -996,6 +996,11 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
 #ifndef DW_C_PREFETCH
 #define DW_C_PREFETCH 1
 #endif
+        float l1w[2][SW];  // weight of the L1 term: 0.15 / 3 where frame f won at pixel q
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int q = 0; q < SW; ++q) l1w[f][q] = (sel[q] == f) ? kWL1 * kThird : 0.f;
 #if DW_C_PREFETCH
         // the coefficient planes of the next channel are read while the current one is summed
         float gbuf[2][3][3][WW];
@@ -1050,10 +1055,9 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
               const float a2 = f ? tot[q][2] - af0[q][2] : af0[q][2];
               const float xq = st[c * QH * QW];
               float gx = fmaf(xq, a1, fmaf(yq, a2, a0));
-              if (sel[q] == f) {
-                const float df = xq - yq;
-                gx += kWL1 * kThird * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
-              }
+              // L1 term where this frame won: 0.15 / 3 with the sign of x - y, nothing at x = y
+              const float df = xq - yq;
+              gx += (df != 0.f) ? __builtin_copysignf(l1w[f][q], df) : 0.f;
               gix[f][q] = fmaf(gx, st[(c + 3) * QH * QW], gix[f][q]);
               giy[f][q] = fmaf(gx, st[(c + 6) * QH * QW], giy[f][q]);
               if (CGRAD) {
@@ -1099,7 +1103,9 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
             const float c2 = fmaf(P[8], X, fmaf(P[9], Y, fmaf(P[10], Z, P[11])));
             const float iz = on ? __builtin_amdgcn_rcpf(c2 + kProjEps) : 0.f;
             const float pu = c0 * iz, pv = c1 * iz;
-            const unsigned vbits = (unsigned)s_valid[win + RP + 1 + q] >> (6 * f);
+            // status byte of the pixel itself: byte q + 1 of the centre row word read above
+            const unsigned vbits = (SW == 2 ? (wrow[1] >> (8 * (q + 1))) & 0xffu
+                                            : (unsigned)s_valid[win + RP + 1 + q]) >> (6 * f);
             const float gu = (on && (vbits & 1)) ? gix[f][q] : 0.f;
             const float gv = (on && (vbits & 2)) ? giy[f][q] : 0.f;
             const float gc0 = gu * iz, gc1 = gv * iz;
