@@ -756,9 +756,16 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       const float X = depth * ((iK[0] * fx + iK[1] * fy) + iK[2]);
       const float Y = depth * ((iK[3] * fx + iK[4] * fy) + iK[5]);
       const float Z = depth * ((iK[6] * fx + iK[7] * fy) + iK[8]);
+      // this lane's projection matrix, from LDS (a per-lane choice between the two
+      // copies in scalar registers would be twelve selects)
       float Pf[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) Pf[k] = q.f ? P1[k] : P0[k];
+      {
+        const float4* Pl = reinterpret_cast<const float4*>(&s_P[q.f][0]);
+        const float4 a = Pl[0], bq = Pl[1], c = Pl[2];
+        Pf[0] = a.x, Pf[1] = a.y, Pf[2] = a.z, Pf[3] = a.w;
+        Pf[4] = bq.x, Pf[5] = bq.y, Pf[6] = bq.z, Pf[7] = bq.w;
+        Pf[8] = c.x, Pf[9] = c.y, Pf[10] = c.z, Pf[11] = c.w;
+      }
       const GlobalFloats srcf = q.f ? src_b[1] : src_b[0];
       sample_addr<GRAD>(H, W, dc, Pf, X, Y, Z, (unsigned)q.f, qa);
       sample_gather(srcf, plane, qa, qt);
