@@ -126,7 +126,7 @@ def main():
         with torch.cuda.graph(graph):
             step()
     if mode == "auto":
-        # untimed probe: a step is five launches, and which of the two ways of issuing them is
+        # untimed probe: a step is four launches, and which of the two ways of issuing them is
         # faster depends on the host; every rank must take the same decision
         def probe(fn, n=30):
             for _ in range(5):
