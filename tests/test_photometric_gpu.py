@@ -291,3 +291,31 @@ def test_color_gradient_matches_committed_golden_vectors():
         got = plan.backward_color()
         for f in range(2):
             assert _rel(got[f].cpu(), torch.from_numpy(gold[f"grad_color{f}"])) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("B,H,W,S,extreme", [(1, 40, 104, 4, False), (2, 32, 96, 2, False), (1, 16, 16, 3, False),
+                                              (2, 32, 96, 4, True)])
+def test_color_gradient_edge_shapes(B, H, W, S, extreme):
+    """Source-image gradient on sizes off the tile grid, with fewer scales, and under a pose that
+    clamps most samples to the image border (the scatter then piles up on border pixels)."""
+    from oracle import photometric as ph
+    from depth_estimation_amd.ops import PhotometricPlan
+    from depth_estimation_amd._lib import DW_FLAG_COLOR_GRAD
+    seq = make_sequence(B, H, W, S=S, seed=H + W + S)
+    if extreme:
+        T = seq.T.clone()
+        T[0, 0, 0, 3] += 25.0
+        T[1, 1, 2, 3] -= 30.0
+        seq.T = T
+    warp_src = [seq.color[1 + f].clone().requires_grad_(True) for f in range(2)]
+    ph.photometric_stack(seq.disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, seq.T, warp_src=warp_src).backward()
+    g = seq.to("cuda")
+    plan = PhotometricPlan(B, H, W, S, "cuda", flags=DW_FLAG_COLOR_GRAD).bind(*g.args())
+    plan.forward(True)
+    got = plan.backward_color()
+    for f in range(2):
+        want = warp_src[f].grad
+        if float(want.abs().max()) == 0.0:
+            assert float(got[f].abs().max()) == 0.0
+        else:
+            assert _rel(got[f].cpu(), want) <= GRAD_RTOL, f"frame {f}: {_rel(got[f].cpu(), want)}"
