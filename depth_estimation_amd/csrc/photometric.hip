@@ -60,7 +60,7 @@ constexpr int SM_NT = 256;
 #define DW_PIPE_A 1
 #endif
 #ifndef DW_GD_PASSES
-#define DW_GD_PASSES 2
+#define DW_GD_PASSES 4
 #endif
 constexpr int GD_PASSES = DW_GD_PASSES;  // coarse-scale pixels per lane group in the backward kernel
 #ifndef DW_XCD_SWIZZLE
