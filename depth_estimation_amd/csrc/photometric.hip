@@ -540,7 +540,8 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
             const float bot = wx0[it][s] * tapv[it][s][2] + wx1[it][s] * tapv[it][s][3];
             du = wy0[it][s] * top + wy1[it][s] * bot;
           }
-          s_depth[s * RN + li] = 1.0f / (kMinDisp + kDispRange * du);
+          const float dsp = kMinDisp + kDispRange * du;
+          s_depth[s * RN + li] = div_by(1.0f, dsp, div_rcp(dsp));  // 1 / dsp
         }
       }
     }
