@@ -632,9 +632,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       }
       // keep the scheduler from interleaving the bodies: that would hold every
       // window of the strip in registers at once
-#ifndef DW_B_NOBARRIER
       __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -1082,9 +1080,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
               }
             }
           }
-#ifndef DW_C_NOBARRIER
           __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         // Branch-free: a pixel without a contribution runs the same arithmetic on
         // zeros (its depth, its gradient and the reciprocal are zeroed), which adds
