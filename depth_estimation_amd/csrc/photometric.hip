@@ -52,6 +52,10 @@ constexpr int SW = DW_SW;    // pixels per thread strip (1 x SW); 1, 2 or 4
 constexpr int WW = SW + 2;   // strip window columns
 constexpr int SPR = QW / SW; // strips per error-map row
 constexpr int BLOCKS_PER_CU = DW_BLOCKS_PER_CU;  // what LDS and registers are budgeted for
+#ifndef DW_FWD_BLOCKS_PER_CU
+#define DW_FWD_BLOCKS_PER_CU 3
+#endif
+constexpr int FWD_BLOCKS_PER_CU = DW_FWD_BLOCKS_PER_CU;  // same, forward-only kernel
 constexpr int RW = QW + 2;   // region columns
 constexpr int RP = QW + 4;  // region row pitch in LDS (16-byte aligned rows)
 constexpr int SM_PX = 1024;  // pixels per block in the per-scale map kernels
@@ -71,7 +75,10 @@ template <bool GRAD>
 struct Geom {
   static constexpr int QH = GRAD ? QH_GRAD : QH_FWD;
   static constexpr int NT = QH * SPR;
-  static constexpr int MINW = NT / 64 * BLOCKS_PER_CU / 4;  // waves per SIMD to stay under
+  // blocks per CU the kernel is compiled for: the forward-only kernel needs less LDS (35 KB) and
+  // runs 5 - 7 % faster with three blocks in 168 registers than with two in 244
+  static constexpr int PER_CU = GRAD ? BLOCKS_PER_CU : FWD_BLOCKS_PER_CU;
+  static constexpr int MINW = NT / 64 * PER_CU / 4;  // waves per SIMD to stay under
   static constexpr int RH = QH + 2;
   static constexpr int CO = GRAD ? 1 : 0;  // core offset inside Q
   static constexpr int CH = QH - 2 * CO;   // core rows = tile step
@@ -1677,17 +1684,17 @@ static int check_desc(const dw_desc* d) {
   return DW_OK;
 }
 
-// Resident-block capacity of the current device for the tile kernels.
-static int tile_slots() {
+// Resident-block capacity of the current device for a tile kernel compiled for `per_cu` blocks per CU.
+static int tile_slots(int per_cu) {
   static int cached[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
   if (cached[dev] == 0) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    cached[dev] = cus * BLOCKS_PER_CU;
+    cached[dev] = cus;
   }
-  return cached[dev];
+  return cached[dev] * per_cu;
 }
 
 // All tiles take the same time, so a launch runs in rounds of `slots` blocks
@@ -1696,9 +1703,9 @@ static int tile_slots() {
 // round, launch them that way: the tail then lasts one scale (plus the
 // scale-independent prologue) instead of S.  Every partial result is indexed
 // by (tile, scale), so the outputs do not depend on the split.
-static int full_blocks(int n_tiles, int S, int flags) {
+static int full_blocks(int n_tiles, int S, int flags, int per_cu) {
   if ((flags & DW_FLAG_NO_TAIL_SPLIT) || S < 2) return n_tiles;
-  const int slots = tile_slots();
+  const int slots = tile_slots(per_cu);
   if (slots <= 0) return n_tiles;
   const int r = n_tiles % slots;
   return ((long)r * S <= slots) ? n_tiles - r : n_tiles;
@@ -1769,7 +1776,7 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   }
 
   const int n_tiles = p.tilesX * p.tilesY * p.B;
-  p.n_full = full_blocks(n_tiles, p.S, desc->flags);
+  p.n_full = full_blocks(n_tiles, p.S, desc->flags, with_grad ? Geom<true>::PER_CU : Geom<false>::PER_CU);
   const dim3 tgrid(p.n_full + (n_tiles - p.n_full) * p.S);
   if (desc->flags & DW_FLAG_TILE_KERNEL_ONLY) {
     if (cgrad)
