@@ -70,3 +70,21 @@ def test_ops_refuse_cpu_tensors():
         ops.photometric_stack(*seq.args())
     with pytest.raises(_lib.DepthwarpError):
         compute_loss(torch.rand(1, 16, 16), torch.rand(1, 16, 16))
+
+
+def test_flags_in_header_and_binding_agree_and_size_the_workspace():
+    text = open(os.path.join(ROOT, "include", "depthwarp.h")).read()
+    flags = {k: int(v) for k, v in re.findall(r"#define\s+(DW_FLAG_\w+)\s+(\d+)", text)}
+    assert flags == {"DW_FLAG_TILE_KERNEL_ONLY": _lib.DW_FLAG_TILE_KERNEL_ONLY,
+                     "DW_FLAG_NO_TAIL_SPLIT": _lib.DW_FLAG_NO_TAIL_SPLIT,
+                     "DW_FLAG_COLOR_GRAD": _lib.DW_FLAG_COLOR_GRAD}
+    lib = _lib.lib()
+    B, H, W = 3, 64, 96
+    plain = lib.dw_photometric_workspace_bytes(_lib.DwDesc(B, H, W, 4, 2, 0))
+    color = lib.dw_photometric_workspace_bytes(_lib.DwDesc(B, H, W, 4, 2, _lib.DW_FLAG_COLOR_GRAD))
+    # two source images, three channels, 64-bit fixed-point sums
+    assert color - plain == 2 * B * 3 * H * W * 8
+    assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(B, H, W, 4, 2, 8)) == 0  # unknown flag
+    # the colour-gradient read-out refuses a descriptor without its flag, before touching any pointer
+    assert lib.dw_photometric_bwd_color(_lib.DwDesc(B, H, W, 4, 2, 0), None, None, 0, None, None) < 0
+    assert lib.dw_photometric_bwd_color(_lib.DwDesc(B, H, W, 4, 2, 4), None, None, 0, None, None) == -1
