@@ -1,21 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: warp + photometric-loss forward/backward throughput.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode op|dp|train]
 
-One step = one fused forward (with gradient stash) + one backward of the
-view-synthesis / photometric-loss stack over one synthetic batch of 3-frame
-sequences: B=12 per GPU, 192x640, 2 source frames, 4 scales.  Inputs are
-resident in HBM before the timed region.  For N > 1 the driver launches one
-rank per GPU (torch.distributed.run); each rank processes its own batch shard
-(weak scaling; the op itself needs no exchange) and the slowest rank sets the
-time.  Rank 0 prints one JSON line.
+--mode op (default)  one step = one fused forward (with gradient stash) + one
+    backward of the view-synthesis / photometric-loss stack over one synthetic
+    batch of 3-frame sequences: B=12 per GPU, 192x640, 2 source frames, 4 scales.
+    Inputs are resident in HBM before the timed region.  The stack shards by
+    batch and has no exchange of its own: with N ranks every rank runs its own
+    shard (weak scaling) and the slowest rank sets the time.
+--mode dp            the data-parallel shard of a training job: B=16 per GPU, and
+    a step also all-reduces (RCCL) what a trainer exchanges -- one flat float32
+    gradient bucket of the networks (3.2 M floats) plus the scalar loss -- after
+    the backward pass.
+--mode train         a whole training step: depth + pose networks (stock PyTorch
+    convolutions), the HIP loss through a pre-allocated plan, backward, the
+    gradient all-reduce and Adam, B=12 per GPU; also reports which share of the
+    step the loss op takes.
+
+With --gpus N > 1 and no launcher in the environment this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`
+as a child (before anything touches the GPU) and relays its JSON line; under a
+launcher (RANK / WORLD_SIZE set) it is one rank.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,25 +40,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+# vector-issue peak: 256 CUs x 4 SIMDs at 2.4 GHz, one plain float32 instruction of a 64-wide wave
+# every 2 cycles per SIMD (instructions counted as SQ_INSTS_VALU counts them, per wave)
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0
+DP_BUCKET_FLOATS = 3_200_000  # gradient bucket of the depth + pose networks (about 12.8 MB)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=12, help="sequences per GPU")
+    ap.add_argument("--mode", choices=["op", "dp", "train"], default="op")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default 12; 16 in dp mode)")
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
                     help="replay a captured HIP graph, issue the launches eagerly, or (auto) probe both "
-                         "during warm-up and time the faster one")
+                         "during warm-up and time the faster one (op mode)")
     ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
+    ap.add_argument("--net-width", type=int, default=64,
+                    help="base channel count of the depth / pose networks in train mode (64: about 4 M parameters)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="sequences in the CPU baseline sample")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = 16 if args.mode == "dp" else 12
+    return args
 
 
+# ------------------------------------------------------------------ launching N ranks
+def launcher_command(n_gpus: int, argv, port: int):
+    """The child command for `--gpus N` without a launcher: one rank per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Runs the ranks as a child job and relays rank 0's JSON line.  Nothing in this
+    process has touched the GPU (importing torch does not)."""
+    cmd = launcher_command(args.gpus, argv, free_port())
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
+
+# ------------------------------------------------------------------ CPU baseline
 def cpu_baseline(args):
     """The CPU oracle (a port: the reference holds no implementation of these
     stages) timed on this host, forward + backward, on a bounded sample."""
@@ -76,45 +129,105 @@ def cpu_baseline(args):
                       f"4 scales, float32, torch CPU threads={cores}"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal on a one-GPU box only: DW_BENCH_REHEARSAL=1 puts every rank on
-    # device 0 and uses gloo for the barrier (RCCL refuses two ranks per device).
-    rehearsal = os.environ.get("DW_BENCH_REHEARSAL") == "1"
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            local = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+# ------------------------------------------------------------------ roofline of the dominant kernel
+def kernel_sources_sha() -> str:
+    """Hash of the sources the tile kernel is built from; counter files carry the hash of the
+    build they were measured on."""
+    h = hashlib.sha256()
+    for rel in ("depth_estimation_amd/csrc/photometric.hip", "depth_estimation_amd/csrc/dw_common.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
+
+def roofline(args, seq, dev, alg_total):
+    """Times the dominant kernel alone (HIP events on its stream) and prices it against the HBM
+    peak by its algorithmic bytes; the vector-issue limit, which is what binds this kernel, is
+    reported beside it from the counters of the last profiler pass over the same sources."""
+    from depth_estimation_amd.ops import PhotometricPlan
+    B, H, W, S = args.batch, args.height, args.width, 4
+    tile_plan = PhotometricPlan(B, H, W, S, dev, flags=1).bind(*seq.args())
+    for _ in range(10):
+        tile_plan.forward(with_grad=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(20, min(args.steps, 200))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        tile_plan.forward(with_grad=True)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / reps
+    achieved = alg_total / (k_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": "photo_tile_kernel<true>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": k_ms,
+           "algorithmic_bytes": alg_total}
+    # Counters cannot be collected from inside the run (the profiler wraps the process): they come
+    # from the committed summary of the last rocprofv3 --pmc passes, and only if that summary was
+    # measured on the sources this library was built from and on this workload.
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    pmc = None
+    if os.path.exists(tpath):
+        try:
+            pmc = json.load(open(tpath))
+        except ValueError:
+            pmc = None
+    limits = [{"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBPS}]
+    if pmc is not None:
+        entry = pmc.get("workloads", {}).get(f"{B}x{H}x{W}")
+        fresh = pmc.get("sources_sha") == kernel_sources_sha()
+        if entry is not None and fresh:
+            out["traffic"] = entry["bytes_corrected"]
+            insts = entry.get("SQ_INSTS_VALU")
+            if insts:
+                rate = insts / (k_ms * 1e-3)
+                limits.append({"bound": "valu_issue", "achieved": rate / 1e12, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e12,
+                               "unit": "T wave-instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S,
+                               "wave_instructions_per_launch": insts})
+        elif entry is not None:
+            out["traffic_stale"] = True  # counters of an older build: not reported
+    out["limits"] = limits
+    out["binding"] = max(limits, key=lambda l: l["frac"])["bound"]
+    return out
+
+
+# ------------------------------------------------------------------ the modes
+def run_op(args, ctx):
+    """Forward (with gradient stash) + backward of the fused stack; dp mode adds the all-reduce."""
     from depth_estimation_amd.synth import make_sequence, algorithmic_bytes
     from depth_estimation_amd.ops import PhotometricPlan
-    from depth_estimation_amd._lib import lib
-
+    dev, dist, rank, world = ctx["dev"], ctx["dist"], ctx["rank"], ctx["world"]
     B, H, W, S = args.batch, args.height, args.width, 4
     seq = make_sequence(B, H, W, S=S, seed=rank).to(dev)
     plan = PhotometricPlan(B, H, W, S, dev).bind(*seq.args())
+    dp = args.mode == "dp"
+    bucket = None
+    if dp:
+        # what a data-parallel trainer exchanges per step: the networks' flat gradient bucket and
+        # the scalar loss in its last slot (depth_estimation_amd/train.py::FlatGradBucket)
+        bucket = torch.zeros(DP_BUCKET_FLOATS + 1, dtype=torch.float32, device="cpu" if ctx["rehearsal"] else dev)
 
-    def step():
+    def op_step():
         plan.forward(with_grad=True)
         plan.backward()
 
+    def dp_step():
+        op_step()
+        if ctx["rehearsal"]:
+            bucket[-1] = float(plan.loss[0])
+        else:
+            bucket[-1:].copy_(plan.loss[:1])
+        if dist is not None:
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        bucket.mul_(1.0 / world)
+
+    step = dp_step if dp else op_step
     for _ in range(3):
         step()
     torch.cuda.synchronize()
 
-    mode = "eager" if args.no_graph else args.launch
+    mode = "eager" if (args.no_graph or dp) else args.launch
     graph = None
     if mode != "eager":
         side = torch.cuda.Stream()
@@ -139,7 +252,7 @@ def main():
             return time.perf_counter() - t
         t_graph, t_eager = probe(graph.replay), probe(step)
         if dist is not None:
-            v = torch.tensor([t_graph, t_eager], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            v = torch.tensor([t_graph, t_eager], dtype=torch.float64, device="cpu" if ctx["rehearsal"] else dev)
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
             t_graph, t_eager = float(v[0]), float(v[1])
         mode = "graph" if t_graph <= t_eager else "eager"
@@ -147,6 +260,96 @@ def main():
         graph = None
     run = step if graph is None else graph.replay
 
+    elapsed = timed(run, args, ctx)
+    alg = algorithmic_bytes(B, H, W, S)
+    per_step = elapsed / args.steps
+    what = ("data-parallel shard: warp+SSIM/L1+smoothness fwd/bwd + all-reduce of a "
+            f"{DP_BUCKET_FLOATS}-float gradient bucket and the loss" if dp else
+            "warp+SSIM/L1+smoothness fwd/bwd microbench")
+    out = {
+        "metric": "warp+photometric-loss fwd+bwd throughput",
+        "value": 3 * B * world / per_step, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{what}, {H}x{W}, batch={B}/GPU, 2 source frames, 4 scales",
+                   "mode": args.mode, "global_batch": B * world,
+                   "launch": "eager" if graph is None else "hip-graph",
+                   "collective": ("all-reduce (sum) of %d floats per step, %s" %
+                                  (DP_BUCKET_FLOATS + 1, "gloo rehearsal" if ctx["rehearsal"] else "RCCL")) if dp
+                   else "none: the stack shards by batch and exchanges nothing"},
+        "hbm_gbps_algorithmic": world * alg["total"] / per_step / 1e9,
+        "loss": float(plan.loss[0].item()),
+    }
+    if dp and world > 1 and not ctx["rehearsal"]:
+        # the collective alone, same payload, for the record
+        for _ in range(5):
+            dist.all_reduce(bucket)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(bucket)
+        torch.cuda.synchronize()
+        out["allreduce_ms"] = 1e3 * (time.perf_counter() - t) / 20
+    if rank == 0:
+        out["roofline"] = roofline(args, seq, dev, alg["total"])
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+    return out
+
+
+def run_train(args, ctx):
+    """Whole training steps of the per-GPU loop (depth_estimation_amd/train.py)."""
+    from depth_estimation_amd.synth import make_sequence, algorithmic_bytes
+    from depth_estimation_amd.train import Trainer
+    from depth_estimation_amd.ops import PhotometricPlan
+    dev, rank, world = ctx["dev"], ctx["rank"], ctx["world"]
+    B, H, W, S = args.batch, args.height, args.width, 4
+    seq = make_sequence(B, H, W, S=S, seed=rank).to(dev)
+    trainer = Trainer(dev, width=args.net_width)
+    for _ in range(3):
+        trainer.step(seq)
+    torch.cuda.synchronize()
+    last = {}
+
+    def step():
+        last["loss"] = trainer.step(seq)
+
+    elapsed = timed(step, args, ctx)
+    per_step = elapsed / args.steps
+    # the loss op alone on the same inputs, for its share of the step
+    with torch.no_grad():
+        disp = [d.detach().contiguous() for d in trainer.depth_net(seq.color[0])]
+    plan = PhotometricPlan(B, H, W, S, dev).bind(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, seq.T)
+    for _ in range(5):
+        plan.forward(True)
+        plan.backward()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        plan.forward(True)
+        plan.backward()
+    e1.record()
+    torch.cuda.synchronize()
+    op_ms = e0.elapsed_time(e1) / 50
+    n_params = sum(p.numel() for p in trainer.bucket.params)
+    alg = algorithmic_bytes(B, H, W, S)
+    return {
+        "metric": "full training step throughput", "value": 3 * B * world / per_step, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"full training step (depth + pose networks on PyTorch-ROCm, HIP warp/loss op, "
+                               f"gradient all-reduce, Adam), {H}x{W}, batch={B}/GPU, 2 source frames, 4 scales",
+                   "mode": "train", "global_batch": B * world, "network_parameters": n_params},
+        "loss": float(last["loss"]),
+        "loss_op_ms": op_ms, "loss_op_share": op_ms / (1e3 * per_step),
+        "hbm_gbps_algorithmic": world * alg["total"] / per_step / 1e9,
+    }
+
+
+def timed(run, args, ctx):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    dist, dev = ctx["dist"], ctx["dev"]
     for _ in range(args.warmup):
         run()
 
@@ -163,69 +366,44 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ctx["rehearsal"] else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(plan.loss[0].item())
+    return elapsed
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    frames = 3 * B * world
-    value = frames / (elapsed / args.steps)
-    alg = algorithmic_bytes(B, H, W, S)
 
-    out = {
-        "metric": "warp+photometric-loss fwd+bwd throughput",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"warp+SSIM/L1+smoothness fwd/bwd microbench, {H}x{W}, "
-                               f"batch={B}/GPU, 2 source frames, 4 scales",
-                   "global_batch": B * world, "launch": "eager" if graph is None else "hip-graph"},
-        "hbm_gbps_algorithmic": world * alg["total"] / (elapsed / args.steps) / 1e9,
-        "loss": loss_val,
-    }
-
-    if rank == 0:
-        # Dominant kernel alone (the per-tile fused kernel), HIP events on the
-        # stream it is launched on.
-        from depth_estimation_amd._lib import DwDesc
-        tile_plan = PhotometricPlan(B, H, W, S, dev, flags=1).bind(*seq.args())
-        for _ in range(10):
-            tile_plan.forward(with_grad=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = max(20, min(args.steps, 200))
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            tile_plan.forward(with_grad=True)
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / reps
-        achieved = alg["total"] / (k_ms * 1e-3) / 1e9
-        traffic = valu_frac = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and (B, H, W) == (12, 192, 640):
-            # HBM bytes and vector instructions per launch from the committed rocprofv3 PMC passes
-            # (bench.py cannot run the profiler on itself); see the file for how they were
-            # collected and corrected
-            pmc = json.load(open(tpath))
-            traffic = pmc["bytes_corrected"]
-            if "SQ_INSTS_VALU" in pmc:
-                # share of the vector-issue peak: 1024 SIMDs, 2 cycles per wave instruction, 2.4 GHz
-                valu_frac = pmc["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9 * k_ms * 1e-3)
-        out["roofline"] = {"bound": "hbm", "kernel": "photo_tile_kernel<true>",
-                           "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                           "kernel_ms": k_ms, "algorithmic_bytes": alg["total"],
-                           "valu_issue_frac": valu_frac}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a one-GPU box only: DW_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and uses gloo for the collectives (RCCL refuses two ranks per device).
+    rehearsal = os.environ.get("DW_BENCH_REHEARSAL") == "1"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if rehearsal:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        local = 0
+        torch.cuda.set_device(0)
+    ctx = {"dev": torch.device("cuda", local), "dist": dist, "rank": rank, "world": world, "rehearsal": rehearsal}
+    out = run_train(args, ctx) if args.mode == "train" else run_op(args, ctx)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

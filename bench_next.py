@@ -99,7 +99,7 @@ def bench_metrics(args):
 
     def fused():
         assert L.dw_compute_loss_metrics_fwd(B, H, W, H, W, gt.data_ptr(), pred.data_ptr(), 1e-3, 128.0,
-                                             out.data_ptr(), ws.data_ptr(), nb, st) == 0
+                                             out.data_ptr(), 0, ws.data_ptr(), nb, st) == 0
         assert L.dw_normalize_image(B, H * W, pred.data_ptr(), out.data_ptr() + 20, 8, img.data_ptr(), None, 0,
                                     st) == 0
 

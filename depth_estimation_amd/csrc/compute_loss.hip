@@ -29,6 +29,7 @@ constexpr int CL_RW = CL_TW + 2 * CL_HALO, CL_RH = CL_TH + 2 * CL_HALO, CL_R = C
 
 struct ClParams {
   int B, Ht, Wt, H, W, tilesX, tilesY;
+  int antialias;  // resize with the area-weighted triangle filter instead of two taps per axis
   const float* target;
   const float* pred;
   float* part;  // [B][tiles][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
@@ -37,6 +38,33 @@ struct ClParams {
   float g[7];   // Gaussian taps
   float clamp_lo, clamp_hi;
 };
+
+// One axis of the anti-aliased bilinear resize (the triangle filter that
+// F.interpolate(mode="bilinear", antialias=True) applies when it shrinks an
+// image): output index `dst` reads the input indices [lo, lo + n) with weight
+// max(0, 1 - |(j + lo - centre + 0.5) / max(scale, 1)|), normalised to sum 1.
+struct AaSpan {
+  int lo, n;
+  float centre, inv, norm;
+  __device__ __forceinline__ float weight(int j) const {
+    const float t = fabsf(((float)(j + lo) - centre + 0.5f) * inv);
+    return (t < 1.0f ? 1.0f - t : 0.f) * norm;
+  }
+};
+__device__ __forceinline__ AaSpan aa_span(int dst, int in_size, float scale) {
+  AaSpan a;
+  const float support = (scale >= 1.0f) ? scale : 1.0f;
+  a.centre = scale * ((float)dst + 0.5f);
+  a.inv = (scale >= 1.0f) ? 1.0f / scale : 1.0f;
+  a.lo = max((int)(a.centre - support + 0.5f), 0);
+  a.n = min((int)(a.centre + support + 0.5f), in_size) - a.lo;
+  a.n = min(max(a.n, 0), (int)ceilf(support) * 2 + 1);
+  a.norm = 1.0f;
+  float total = 0.f;
+  for (int j = 0; j < a.n; ++j) total += a.weight(j);
+  a.norm = (total != 0.f) ? 1.0f / total : 1.0f;
+  return a;
+}
 
 // Minimum / maximum over a block (result in thread 0); `red` holds NT/64 floats.
 template <int NT, bool IS_MAX>
@@ -77,6 +105,16 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_tile_kernel(const ClParams
     float t;
     if (same) {
       t = tg[(long)y * W + x];
+    } else if (p.antialias) {
+      // rows of the input first (horizontal pass), then the weighted rows (vertical pass)
+      const AaSpan ay = aa_span(y, p.Ht, sy), ax = aa_span(x, p.Wt, sx);
+      t = 0.f;
+      for (int j = 0; j < ay.n; ++j) {
+        const float* row = tg + (long)(ay.lo + j) * p.Wt + ax.lo;
+        float h = 0.f;
+        for (int k = 0; k < ax.n; ++k) h = fmaf(ax.weight(k), row[k], h);
+        t = fmaf(ay.weight(j), h, t);
+      }
     } else {
       const Taps ty = upsample_taps(y, p.Ht, sy), tx = upsample_taps(x, p.Wt, sx);
       const float v00 = tg[(long)ty.i0 * p.Wt + tx.i0], v01 = tg[(long)ty.i0 * p.Wt + tx.i1];
@@ -346,8 +384,9 @@ extern "C" size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t 
 template <bool METRICS>
 static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
                                const float* target, const float* pred, float clamp_lo, float clamp_hi,
-                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                               float* out, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
   if (!target || !pred || !out || !workspace) return DW_ERR_NULL;
+  if (flags & ~DW_CL_FLAG_ANTIALIAS) return DW_ERR_ARG;
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
   if (workspace_bytes < dw_compute_loss_workspace_bytes(B, H, W) || ((uintptr_t)workspace & 255))
@@ -360,6 +399,7 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   p.W = W;
   p.tilesX = (W + CL_TW - 1) / CL_TW;
   p.tilesY = (H + CL_TH - 1) / CL_TH;
+  p.antialias = (flags & DW_CL_FLAG_ANTIALIAS) ? 1 : 0;
   p.target = target;
   p.pred = pred;
   p.part = (float*)workspace;
@@ -380,18 +420,18 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
 }
 
 extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                                   const float* target, const float* pred, float* out,
+                                   const float* target, const float* pred, float* out, int32_t flags,
                                    void* workspace, size_t workspace_bytes, void* stream) {
-  return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, workspace,
+  return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, flags, workspace,
                                     workspace_bytes, stream);
 }
 
 extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
                                            const float* target, const float* pred, float clamp_min,
-                                           float clamp_max, float* out, void* workspace,
+                                           float clamp_max, float* out, int32_t flags, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   if (!(clamp_min <= clamp_max)) return DW_ERR_ARG;
-  return compute_loss_launch<true>(B, Ht, Wt, H, W, target, pred, clamp_min, clamp_max, out, workspace,
+  return compute_loss_launch<true>(B, Ht, Wt, H, W, target, pred, clamp_min, clamp_max, out, flags, workspace,
                                    workspace_bytes, stream);
 }
 

@@ -1480,7 +1480,8 @@ struct BwdParams {
   int tilesX, tilesY;
   const float* disp[DW_MAX_SCALES];
   const float* K;
-  const float* grad_loss;
+  const float* grad_loss;  // upstream gradient of loss_out: [0] the total; with g_len = 1 + 2S also
+  int g_len;               // [1 + s] of L_photo[s] and [1 + S + s] of L_sm[s]
   const float* tile_dP;
   const float* gdup;
   const float* img_scal;
@@ -1516,8 +1517,12 @@ __device__ __forceinline__ void grad_disp_block(const BwdParams& p, int blk) {
   const float sum_gd = p.img_scal[2 * (s * p.B + b) + 1];  // sum_i G_i * disp_i over the image
   const float go = p.grad_loss[0];
   const float inv = 1.0f / (mean + kMeanEps);
-  const float coef = go * (kWSmooth / (float)(1 << s)) / (float)p.S;
-  const float g0 = go / ((float)p.S * (float)p.B * (float)plane);
+  float coef = go * (kWSmooth / (float)(1 << s)) / (float)p.S;
+  float g0 = go / ((float)p.S * (float)p.B * (float)plane);
+  if (p.g_len > 1) {  // the per-scale terms have upstream gradients of their own
+    coef += p.grad_loss[1 + p.S + s];
+    g0 = (go / (float)p.S + p.grad_loss[1 + s]) / ((float)p.B * (float)plane);
+  }
   const float mean_term = sum_gd * inv * inv / (float)n;
   const float* G = p.sm_G + p.L.pix_off[s] + (long)b * n;
   const float* gup = p.gdup + ((long)s * p.B + b) * plane;
@@ -1572,12 +1577,25 @@ __device__ __forceinline__ void grad_pose_block(const BwdParams& p, int b) {
   __shared__ double s_dP[24];
   const int tid = threadIdx.x;
   const int nrow = p.tilesX * p.tilesY * p.S;  // one row of 24 partials per (tile, scale)
+  // weight of the rows of scale s: 1 when only the total has an upstream gradient (it is
+  // applied to the sum below), else the upstream gradient that reaches L_photo[s]
+  double wsc[DW_MAX_SCALES];
+#pragma unroll
+  for (int s = 0; s < DW_MAX_SCALES; ++s)
+    wsc[s] = (p.g_len > 1 && s < p.S) ? (double)p.grad_loss[0] / (double)p.S + (double)p.grad_loss[1 + s] : 1.0;
   if (tid < GP_GROUPS * 24) {
     const int g = tid / 24, k = tid - g * 24;
     double a = 0.0;
     const float* src = p.tile_dP + (long)b * nrow * 24 + k;
+    int sc = g % p.S;  // row t belongs to scale t % S
+    const int step = GP_GROUPS % p.S;
 #pragma unroll 8
-    for (int t = g; t < nrow; t += GP_GROUPS) a += (double)src[(long)t * 24];
+    for (int t = g; t < nrow; t += GP_GROUPS) {
+      const double w = (sc == 0) ? wsc[0] : (sc == 1) ? wsc[1] : (sc == 2) ? wsc[2] : wsc[3];
+      a += w * (double)src[(long)t * 24];
+      sc += step;
+      sc -= (sc >= p.S) ? p.S : 0;
+    }
     s_part[g][k] = a;
   }
   __syncthreads();
@@ -1592,7 +1610,8 @@ __device__ __forceinline__ void grad_pose_block(const BwdParams& p, int b) {
     const float* Kb = p.K + (long)b * 16;
     double a = 0.0;
     for (int i = 0; i < 3; ++i) a += (double)Kb[i * 4 + k] * s_dP[f * 12 + i * 4 + j];
-    const double g0 = (double)p.grad_loss[0] / ((double)p.S * p.B * p.H * p.W);
+    const double g0 = (p.g_len > 1) ? 1.0 / ((double)p.B * p.H * p.W)
+                                    : (double)p.grad_loss[0] / ((double)p.S * p.B * p.H * p.W);
     p.grad_T[((long)b * DW_NUM_SRC + f) * 16 + k * 4 + j] = (float)(a * g0);
   }
 }
@@ -1680,7 +1699,8 @@ static int check_desc(const dw_desc* d) {
   const int m = 1 << (d->S - 1);
   if (d->H % m || d->W % m) return DW_ERR_SHAPE;
   if ((d->H >> (d->S - 1)) < 2 || (d->W >> (d->S - 1)) < 2) return DW_ERR_SHAPE;
-  if ((long)d->H * d->W > (1l << 30) || d->B > 65535) return DW_ERR_SHAPE;
+  // byte offsets inside a colour plane ((y * W + x) * 4) and H * W itself are 32-bit in the kernels
+  if ((long)d->H * d->W > (1l << 28) || d->B > 65535) return DW_ERR_SHAPE;
   return DW_OK;
 }
 
@@ -1803,12 +1823,13 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
 }
 
 extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp, const float* K,
-                                  const float* grad_loss, const void* workspace,
+                                  const float* grad_loss, int32_t grad_loss_len, const void* workspace,
                                   size_t workspace_bytes, float* const* grad_disp, float* grad_T,
                                   void* stream) {
   int rc = check_desc(desc);
   if (rc != DW_OK) return rc;
   if (!disp || !K || !grad_loss || !workspace || !grad_disp) return DW_ERR_NULL;
+  if (grad_loss_len != 1 && grad_loss_len != 1 + 2 * desc->S) return DW_ERR_ARG;
   BwdParams p{};
   WsLayout w;
   TileCounts tc;
@@ -1828,6 +1849,7 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
 
   p.K = K;
   p.grad_loss = grad_loss;
+  p.g_len = grad_loss_len;
   const char* ws = (const char*)workspace;
   p.tile_dP = (const float*)(ws + w.tile_dP);
   p.gdup = (const float*)(ws + w.gdup);

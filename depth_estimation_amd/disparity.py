@@ -4,8 +4,10 @@ Replaces the tail of `DepthBlock.forward` in the reference
 (/root/reference/model/model.py:454-456 `view` + `softmax(-out, 1)`, then
 :417-429 squeeze, a second `softmax(-prob, 0)`, multiplication with a
 materialised disparity grid and the sum): `soft_argmin(out)` takes the
-de-convolution output viewed as (B, D, H, W) and returns the (B, 1, H, W)
-disparity; batch 1 reproduces the reference's (1, H, W) map.  Differentiable
+de-convolution output viewed as (B, D, H, W) and returns the (B, H, W)
+disparity: at batch 1 that is the reference's (1, H, W) map (model.py:428, a sum over
+dim 0 with keepdim after the squeeze), which its callers hand on to 3-D consumers
+such as `to_pil_image` (model.py:235).  Differentiable
 (the backward recomputes the forward from the cost volume; nothing is saved).
 """
 from __future__ import annotations
@@ -78,5 +80,5 @@ _soft_argmin.register_autograd(_backward, setup_context=_setup)
 
 
 def soft_argmin(cost: Tensor) -> Tensor:
-    """cost (B, D, H, W), D <= 256 -> disparity (B, 1, H, W) in [0, D-1]."""
-    return _soft_argmin(cost)
+    """cost (B, D, H, W), D <= 256 -> disparity (B, H, W) in [0, D-1]."""
+    return _soft_argmin(cost)[:, 0]

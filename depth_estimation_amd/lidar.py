@@ -5,7 +5,7 @@ Mirrors `Dataset.generate_depth_map` of the reference
 `read_calib_file` (:167-186) and `load_velodyne_points` (:188-194).  The
 projection, the in-bounds filter and the sparse nearest-depth map run in one
 batched HIP call (`project_scans`); calibration parsing and the Delaunay hole
-filling (`lin_interp`, :155-165, SciPy) stay on the host as in the reference.
+filling (`fill_holes`; the reference's `lin_interp`, :155-165, SciPy) stay on the host as in the reference.
 """
 from __future__ import annotations
 
@@ -19,7 +19,7 @@ from torch import Tensor
 from . import _lib
 
 __all__ = ["read_calib_file", "load_velodyne_points", "velo_to_image_matrix", "project_scans",
-           "lin_interp", "generate_depth_map", "synthetic_scan", "KITTI_LIKE_CALIB"]
+           "fill_holes", "generate_depth_map", "synthetic_scan", "KITTI_LIKE_CALIB"]
 
 
 def read_calib_file(path: str) -> dict:
@@ -39,10 +39,15 @@ def read_calib_file(path: str) -> dict:
 
 
 def load_velodyne_points(filename: str) -> np.ndarray:
-    """(N, 4) float32 rows forward, left, up, 1 (:188-194)."""
-    points = np.fromfile(filename, dtype=np.float32).reshape(-1, 4)
-    points[:, 3] = 1.0
-    return points
+    """KITTI scan file (little-endian float32 quadruples forward, left, up,
+    reflectance) -> (N, 4) float32 rows with the reflectance replaced by the
+    homogeneous 1, the array `generate_depth_map` of the reference works on (:188-194)."""
+    raw = np.fromfile(filename, dtype="<f4")
+    if raw.size % 4:
+        raise ValueError(f"{filename}: {raw.size} floats is not a whole number of (x, y, z, r) records")
+    scan = np.ascontiguousarray(raw.reshape(raw.size // 4, 4), dtype=np.float32)
+    scan[:, 3] = 1.0
+    return scan
 
 
 def velo_to_image_matrix(cam2cam: dict, velo2cam: dict, cam: int = 2) -> np.ndarray:
@@ -94,15 +99,17 @@ def project_scans(points: Tensor, n_points: Tensor, P: Tensor, im_shape: Tuple[i
     return pts_im, n_valid, depth
 
 
-def lin_interp(shape, xyd: np.ndarray) -> np.ndarray:
-    """Delaunay hole filling on the host (:155-165; SciPy, as in the reference)."""
+def fill_holes(shape, pts_im: np.ndarray) -> np.ndarray:
+    """Dense map from the kept points (x, y, z) of one scan: piecewise-linear
+    interpolation of z over the Delaunay triangulation of the (row, column)
+    positions, 0 outside their convex hull -- the host-side stage that follows the
+    projection in the reference (:151, :155-165).  Out of the GPU path: SciPy does it."""
     from scipy.interpolate import LinearNDInterpolator
-    m, n = shape
-    ij, d = xyd[:, 1::-1], xyd[:, 2]
-    f = LinearNDInterpolator(ij, d, fill_value=0)
-    J, I = np.meshgrid(np.arange(n), np.arange(m))
-    IJ = np.vstack([I.flatten(), J.flatten()]).T
-    return f(IJ).reshape(shape)
+    rows_cols = np.stack([pts_im[:, 1], pts_im[:, 0]], axis=1)
+    surface = LinearNDInterpolator(rows_cols, pts_im[:, 2], fill_value=0.0)
+    height, width = int(shape[0]), int(shape[1])
+    queries = np.indices((height, width)).reshape(2, height * width).T
+    return surface(queries).reshape(height, width)
 
 
 def generate_depth_map(calib_path: str, velo_filename: str, interp: bool = True, cam: int = 2,
@@ -126,7 +133,7 @@ def generate_depth_map(calib_path: str, velo_filename: str, interp: bool = True,
     if not interp:
         return depth[0].cpu().numpy()
     xyd = pts_im[0, :int(n_valid[0])].cpu().numpy()
-    return lin_interp((int(im_shape[0]), int(im_shape[1])), xyd)
+    return fill_holes((int(im_shape[0]), int(im_shape[1])), xyd)
 
 
 # Calibration of the shape KITTI publishes (rectified camera 2, 1242 x 375).

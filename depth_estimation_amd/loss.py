@@ -29,7 +29,7 @@ def _as_b1hw(name: str, t: Tensor) -> Tensor:
 
 
 @torch.library.custom_op("depthwarp::compute_loss_fwd", mutates_args=())
-def compute_loss_fwd(target: Tensor, pred: Tensor) -> Tensor:
+def compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
     """target (B,1,Ht,Wt), pred (B,1,H,W), float32 -> (B,4): loss, ssim_term, l1, smooth."""
     if not (target.is_cuda and pred.is_cuda):
         raise _lib.DepthwarpError("compute_loss: expected ROCm device tensors "
@@ -48,18 +48,19 @@ def compute_loss_fwd(target: Tensor, pred: Tensor) -> Tensor:
     with torch.cuda.device(pred.device):
         rc = lib.dw_compute_loss_fwd(B, target.shape[2], target.shape[3], H, W,
                                      target.data_ptr(), pred.data_ptr(), out.data_ptr(),
-                                     ws.data_ptr(), nbytes,
+                                     _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0, ws.data_ptr(), nbytes,
                                      torch.cuda.current_stream(pred.device).cuda_stream)
     _lib.check(rc, "dw_compute_loss_fwd")
     return out
 
 
 @compute_loss_fwd.register_fake
-def _(target, pred):
+def _(target, pred, antialias=False):
     return torch.empty((pred.shape[0], 4), dtype=torch.float32, device=pred.device)
 
 
-def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: int = None):
+def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: int = None,
+                       antialias: bool = False):
     """Per-sample terms as a dict of (B,) tensors: loss, ssim_term, l1, smooth."""
     with torch.no_grad():
         pred = _as_b1hw("pred", pred)
@@ -68,12 +69,19 @@ def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: 
             # the reference's `pred.view(1, 1, H, W)` raises on a size mismatch
             raise RuntimeError(f"pred has shape {tuple(pred.shape)}, expected (*,1,{height},{width})")
         # the reference hands over a float64 target (NumPy pipeline); compute in float32
-        out = compute_loss_fwd(target.float(), pred.float())
+        out = compute_loss_fwd(target.float(), pred.float(), antialias)
     return {"loss": out[:, 0], "ssim_term": out[:, 1], "l1": out[:, 2], "smooth": out[:, 3]}
 
 
-def compute_loss(target: Tensor, pred: Tensor, height: int = None, width: int = None) -> Tensor:
+def compute_loss(target: Tensor, pred: Tensor, height: int = None, width: int = None,
+                 antialias: bool = False) -> Tensor:
     """Drop-in for `Train.compute_loss(target, pred)`; the output size is
-    `pred`'s (the reference reads it from `Config.height/width`)."""
-    loss = compute_loss_terms(target, pred, height, width)["loss"]
+    `pred`'s (the reference reads it from `Config.height/width`).
+
+    `antialias` selects how the ground truth is shrunk (train.py:276 calls
+    torchvision's `resize`, whose tensor default is the plain bilinear resize in
+    some releases and the anti-aliased one in others; the reference pins no
+    version): False = two taps per axis, True = area-weighted triangle filter
+    (`F.interpolate(..., antialias=True)`)."""
+    loss = compute_loss_terms(target, pred, height, width, antialias)["loss"]
     return loss[0] if loss.numel() == 1 else loss

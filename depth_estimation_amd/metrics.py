@@ -37,7 +37,8 @@ def _scalar_if_single(t: Tensor) -> Tensor:
 
 
 @torch.library.custom_op("depthwarp::compute_loss_metrics_fwd", mutates_args=())
-def _loss_metrics(target: Tensor, pred: Tensor, clamp_min: float, clamp_max: float) -> Tensor:
+def _loss_metrics(target: Tensor, pred: Tensor, clamp_min: float, clamp_max: float,
+                  antialias: bool = False) -> Tensor:
     """target (B,1,Ht,Wt), pred (B,1,H,W) -> (B,8)."""
     _need_cuda(target, pred)
     B, _, H, W = pred.shape
@@ -53,32 +54,34 @@ def _loss_metrics(target: Tensor, pred: Tensor, clamp_min: float, clamp_max: flo
     with torch.cuda.device(pred.device):
         rc = lib.dw_compute_loss_metrics_fwd(B, target.shape[2], target.shape[3], H, W, target.data_ptr(),
                                              pred.data_ptr(), clamp_min, clamp_max, out.data_ptr(),
+                                             _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0,
                                              ws.data_ptr(), nbytes, _stream(pred))
     _lib.check(rc, "dw_compute_loss_metrics_fwd")
     return out
 
 
 @_loss_metrics.register_fake
-def _(target, pred, clamp_min, clamp_max):
+def _(target, pred, clamp_min, clamp_max, antialias=False):
     return torch.empty((pred.shape[0], 8), dtype=torch.float32, device=pred.device)
 
 
-def compute_loss_and_metrics(target: Tensor, pred: Tensor, maxdisp: float = MAXDISP) -> dict:
+def compute_loss_and_metrics(target: Tensor, pred: Tensor, maxdisp: float = MAXDISP,
+                             antialias: bool = False) -> dict:
     """One pass: dict of (B,) tensors loss, ssim_term, l1, smooth (train.py:272-309),
     rmse (train.py:311-343, one side) and pred_min / pred_max (train.py:250-251)."""
     with torch.no_grad():
         out = _loss_metrics(_as_b1hw("target", target).float(), _as_b1hw("pred", pred).float(),
-                            1e-3, float(maxdisp))
+                            1e-3, float(maxdisp), antialias)
     names = ("loss", "ssim_term", "l1", "smooth", "rmse", "pred_min", "pred_max")
     return {k: out[:, i] for i, k in enumerate(names)}
 
 
-def compute_errors(inputs: dict, outputs: dict, maxdisp: float = MAXDISP):
+def compute_errors(inputs: dict, outputs: dict, maxdisp: float = MAXDISP, antialias: bool = False):
     """Drop-in for `Train.compute_errors(inputs, outputs)`: (left_rmse, right_rmse).
     The output size is the prediction's (the reference reads Config.height/width)."""
     res = []
     for side in ("l", "r"):
-        m = compute_loss_and_metrics(inputs[f"{side}_depth"], outputs[f"{side}_pred"], maxdisp)
+        m = compute_loss_and_metrics(inputs[f"{side}_depth"], outputs[f"{side}_pred"], maxdisp, antialias)
         res.append(_scalar_if_single(m["rmse"]))
     return res[0], res[1]
 

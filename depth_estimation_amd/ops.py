@@ -15,7 +15,7 @@ from torch import Tensor
 from . import _lib
 from ._lib import DwDesc, DW_NUM_SRC, DW_FLAG_COLOR_GRAD
 
-__all__ = ["photometric_stack", "photometric_forward", "workspace_bytes"]
+__all__ = ["photometric_stack", "photometric_forward", "workspace_bytes", "PhotometricPlan", "PlanLoss"]
 
 
 def _stream(device) -> int:
@@ -111,6 +111,8 @@ def photometric_bwd(disp: Sequence[Tensor], K: Tensor, grad_loss: Tensor, worksp
     desc = DwDesc(B, height, width, S, DW_NUM_SRC, 0)
     dev = disp[0].device
     _check_f32("grad_loss", grad_loss)
+    if grad_loss.numel() not in (1, 1 + 2 * S):
+        raise ValueError(f"grad_loss: expected 1 or {1 + 2 * S} elements, got {grad_loss.numel()}")
     sizes = [d.numel() for d in disp]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
     views, o = [], 0
@@ -120,7 +122,7 @@ def photometric_bwd(disp: Sequence[Tensor], K: Tensor, grad_loss: Tensor, worksp
     grad_T = torch.empty((B, DW_NUM_SRC, 4, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().dw_photometric_bwd(
-            desc, _lib.ptr_array(disp), K.data_ptr(), grad_loss.data_ptr(),
+            desc, _lib.ptr_array(disp), K.data_ptr(), grad_loss.data_ptr(), grad_loss.numel(),
             workspace.data_ptr(), workspace.numel(), _lib.ptr_array(views),
             grad_T.data_ptr(), _stream(dev))
     _lib.check(rc, "dw_photometric_bwd")
@@ -151,8 +153,7 @@ def _backward(ctx, g_loss, g_mask, g_ws):
                            "no backward state was kept")
     saved = ctx.saved_tensors
     disp, K, ws = list(saved[:ctx.S]), saved[ctx.S], saved[ctx.S + 1]
-    # Only the total (element 0) is a differentiable output; the per-scale
-    # terms after it are reporting copies.
+    # g_loss has 1 + 2S entries: the upstream gradient of the total and of every per-scale term
     flat, grad_T = photometric_bwd(disp, K, g_loss.contiguous(), ws, ctx.hw[0], ctx.hw[1])
     grads, o = [], 0
     for d in disp:
@@ -165,8 +166,8 @@ photometric_fwd.register_autograd(_backward, setup_context=_setup_context)
 
 
 def photometric_forward(disp, color, color_pyr, K, inv_K, T, tie_noise=None):
-    """Returns (loss_terms, mask). loss_terms[0] is the differentiable total;
-    [1:1+S] are L_photo per scale, [1+S:] L_smooth per scale. mask[s] packs the
+    """Returns (loss_terms, mask). loss_terms[0] is the total, [1:1+S] are L_photo
+    per scale, [1+S:] L_smooth per scale (all differentiable). mask[s] packs the
     arg-min index (bits 0-1) and the validity of each source (bits 2, 3)."""
     need = torch.is_grad_enabled() and (any(d.requires_grad for d in disp) or T.requires_grad)
     terms, mask, _ = photometric_fwd(list(disp), list(color), list(color_pyr), K, inv_K, T,
@@ -225,19 +226,23 @@ class PhotometricPlan:
 
     def forward(self, with_grad: bool = True, stream: Optional[int] = None):
         d, c, py, K, iK, T, tie = self._p
-        rc = self._lib.dw_photometric_fwd(self.desc, d, c, py, K, iK, T, tie, self._mask_ptrs,
-                                          self.loss.data_ptr(), self.ws.data_ptr(), self.nbytes,
-                                          1 if with_grad else 0,
-                                          _stream(self.device) if stream is None else stream)
+        # the host side sizes its launch from the current device, and the stream belongs to it
+        with torch.cuda.device(self.device):
+            rc = self._lib.dw_photometric_fwd(self.desc, d, c, py, K, iK, T, tie, self._mask_ptrs,
+                                              self.loss.data_ptr(), self.ws.data_ptr(), self.nbytes,
+                                              1 if with_grad else 0,
+                                              _stream(self.device) if stream is None else stream)
         _lib.check(rc, "dw_photometric_fwd")
         return self.loss
 
     def backward(self, grad_loss: Optional[Tensor] = None, stream: Optional[int] = None):
+        """`grad_loss`: one element (upstream gradient of the total) or 1 + 2S (of every loss term)."""
         g = self.one if grad_loss is None else grad_loss
-        rc = self._lib.dw_photometric_bwd(self.desc, self._p[0], self._p[3], g.data_ptr(),
-                                          self.ws.data_ptr(), self.nbytes, self._gd_ptrs,
-                                          self.grad_T.data_ptr(),
-                                          _stream(self.device) if stream is None else stream)
+        with torch.cuda.device(self.device):
+            rc = self._lib.dw_photometric_bwd(self.desc, self._p[0], self._p[3], g.data_ptr(), g.numel(),
+                                              self.ws.data_ptr(), self.nbytes, self._gd_ptrs,
+                                              self.grad_T.data_ptr(),
+                                              _stream(self.device) if stream is None else stream)
         _lib.check(rc, "dw_photometric_bwd")
         return self.grad_disp, self.grad_T
 
@@ -247,8 +252,62 @@ class PhotometricPlan:
         if self.grad_color is None:
             raise _lib.DepthwarpError("this plan was built without DW_FLAG_COLOR_GRAD")
         g = self.one if grad_loss is None else grad_loss
-        rc = self._lib.dw_photometric_bwd_color(self.desc, g.data_ptr(), self.ws.data_ptr(), self.nbytes,
-                                                self._gc_ptrs,
-                                                _stream(self.device) if stream is None else stream)
+        with torch.cuda.device(self.device):
+            rc = self._lib.dw_photometric_bwd_color(self.desc, g.data_ptr(), self.ws.data_ptr(), self.nbytes,
+                                                    self._gc_ptrs,
+                                                    _stream(self.device) if stream is None else stream)
         _lib.check(rc, "dw_photometric_bwd_color")
         return self.grad_color
+
+
+class _PlanFunction(torch.autograd.Function):
+    """autograd node over a bound PhotometricPlan: forward and backward are the raw C-ABI
+    calls on the plan's pre-allocated buffers."""
+
+    @staticmethod
+    def forward(ctx, plan, need_grad, T, *disp):
+        plan.forward(with_grad=need_grad)
+        plan.generation += 1
+        ctx.plan, ctx.generation, ctx.need_grad = plan, plan.generation, need_grad
+        ctx.mark_non_differentiable(plan.mask)
+        return plan.loss.clone(), plan.mask
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_mask):
+        plan = ctx.plan
+        if not ctx.need_grad:
+            raise RuntimeError("the loss was evaluated without gradients; no backward state was kept")
+        if plan.generation != ctx.generation:
+            raise RuntimeError("the plan ran another forward pass since this loss was computed: its "
+                               "workspace holds the later call (one loss per plan and step)")
+        grad_disp, grad_T = plan.backward(g_loss.contiguous())
+        return (None, None, grad_T, *grad_disp)
+
+
+class PlanLoss:
+    """`photometric_stack` with pre-allocated state: the same call signature, but the
+    workspace, masks and gradient buffers belong to a PhotometricPlan per problem shape and
+    are reused by every step (nothing of that size is allocated per call, and a step is the
+    two raw library calls).  The returned gradients alias the plan's buffers: consume them --
+    as autograd does when it runs the networks' backward -- before the next forward pass of the
+    same shape.  One loss per shape may be pending at a time."""
+
+    def __init__(self):
+        self._plans = {}
+        self.last_mask = None
+
+    def terms(self, disp, color, color_pyr, K, inv_K, T, tie_noise=None):
+        B, _, H, W = color[0].shape
+        key = (B, H, W, len(disp), color[0].device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = PhotometricPlan(B, H, W, len(disp), color[0].device)
+            plan.generation = 0
+        plan.bind([d.detach() for d in disp], color, color_pyr, K, inv_K, T.detach(), tie_noise)
+        need = torch.is_grad_enabled() and (any(d.requires_grad for d in disp) or T.requires_grad)
+        terms, mask = _PlanFunction.apply(plan, need, T, *disp)
+        self.last_mask = mask
+        return terms
+
+    def __call__(self, disp, color, color_pyr, K, inv_K, T, tie_noise=None) -> Tensor:
+        return self.terms(disp, color, color_pyr, K, inv_K, T, tie_noise)[0]

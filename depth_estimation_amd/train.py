@@ -108,8 +108,8 @@ class Trainer:
                 from ._lib import DepthwarpError
                 raise DepthwarpError("the view-synthesis loss runs on ROCm GPUs only; pass loss_fn "
                                      "explicitly to drive the loop on another device")
-            from .ops import photometric_stack
-            loss_fn = photometric_stack
+            from .ops import PlanLoss
+            loss_fn = PlanLoss()  # pre-allocated workspace and gradient buffers, reused every step
         self.loss_fn = loss_fn
         torch.manual_seed(seed)  # identical initial weights on every rank
         self.depth_net = DepthNet(width).to(self.device)

@@ -37,7 +37,7 @@ extern "C" {
 #define DW_API
 #endif
 
-#define DW_VERSION 1
+#define DW_VERSION 2
 #define DW_MAX_SCALES 4
 #define DW_NUM_SRC 2
 
@@ -51,7 +51,8 @@ enum {
 };
 
 /* Problem description of the photometric stack. Scale s has H>>s x W>>s
- * pixels; H and W must be divisible by 2^(S-1); F must be DW_NUM_SRC. */
+ * pixels; H and W must be divisible by 2^(S-1); F must be DW_NUM_SRC;
+ * H * W <= 2^28 and B <= 65535. */
 typedef struct dw_desc {
   int32_t B; /* samples (3-frame sequences)                 */
   int32_t H; /* full-resolution height                      */
@@ -117,14 +118,16 @@ DW_API int dw_photometric_fwd(const dw_desc* desc,
                        int with_grad, void* stream);
 
 /* Backward of the call above (same desc, same workspace, untouched since).
- *   grad_loss     device scalar: upstream gradient of the total loss
+ *   grad_loss     device floats, upstream gradient of loss_out: grad_loss_len = 1
+ *                 (of the total only) or 1 + 2*S (of every entry: a loss built
+ *                 from the per-scale terms L_photo[s], L_sm[s] is differentiated too)
  *   grad_disp[s]  (B,1,H>>s,W>>s) out (overwritten)
  *   grad_T        (B,F,4,4) out (overwritten); may be NULL
  */
 DW_API int dw_photometric_bwd(const dw_desc* desc,
                        const float* const* disp,
                        const float* K,
-                       const float* grad_loss,
+                       const float* grad_loss, int32_t grad_loss_len,
                        const void* workspace, size_t workspace_bytes,
                        float* const* grad_disp,
                        float* grad_T,
@@ -151,15 +154,21 @@ DW_API int dw_photometric_bwd_color(const dw_desc* desc,
  * Batched: sample b of the result equals the reference's batch-1 call on
  * sample b.
  *   target   (B,1,Ht,Wt)  ground truth, resized to (H,W) inside (bilinear,
- *            align_corners=False, no antialias; train.py:276)
+ *            align_corners=False; train.py:276)
  *   pred     (B,1,H,W)
  *   out      (B,4) floats: loss, ssim_term, l1, smooth   (train.py:299-307)
+ *   flags    0, or DW_CL_FLAG_ANTIALIAS: the resize of train.py:276 is
+ *            torchvision's, whose default for tensors is a plain two-tap
+ *            bilinear resize in some releases and the anti-aliased (area
+ *            weighted triangle filter) one in others; the flag selects the latter
  *   workspace: dw_compute_loss_workspace_bytes(B,H,W) bytes
  * ------------------------------------------------------------------------- */
+#define DW_CL_FLAG_ANTIALIAS 1
+
 DW_API size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
 
 DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                        const float* target, const float* pred, float* out,
+                        const float* target, const float* pred, float* out, int32_t flags,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same pass, additionally producing the evaluation metrics the reference
@@ -172,7 +181,7 @@ DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
  */
 DW_API int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
                                 const float* target, const float* pred, float clamp_min,
-                                float clamp_max, float* out, void* workspace,
+                                float clamp_max, float* out, int32_t flags, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
 /* Train.normalize_image, train.py:248-253, per sample and without the two

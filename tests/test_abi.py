@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
 
 def test_version_and_error_strings():
     lib = _lib.lib()
-    assert lib.dw_version() == 1
+    assert lib.dw_version() == 2
     assert lib.dw_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -5):
         assert len(lib.dw_strerror(code)) > 3
@@ -43,6 +43,9 @@ def test_workspace_sizes_and_shape_checks():
     assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(1, 100, 640, 4, 2, 0)) == 0  # 100 % 8 != 0
     assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(1, 192, 640, 5, 2, 0)) == 0
     assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(1, 192, 640, 4, 3, 0)) == 0
+    # H * W <= 2^28 (32-bit byte offsets inside a colour plane): one row more is refused
+    assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(1, 16384, 16384, 4, 2, 0)) > 0
+    assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(1, 16384, 16392, 4, 2, 0)) == 0
     assert lib.dw_compute_loss_workspace_bytes(1, 256, 512) > 0
     assert lib.dw_compute_loss_workspace_bytes(1, 2, 512) == 0
 
@@ -55,7 +58,7 @@ def test_null_and_bad_arguments_return_codes_without_launching():
     bad = _lib.DwDesc(1, 33, 64, 4, 2, 0)
     rc = lib.dw_photometric_fwd(bad, None, None, None, None, None, None, None, None, None, None, 0, 1, None)
     assert rc == -2
-    assert lib.dw_compute_loss_fwd(1, 8, 8, 8, 8, None, None, None, None, 0, None) == -1
+    assert lib.dw_compute_loss_fwd(1, 8, 8, 8, 8, None, None, None, 0, None, 0, None) == -1
     with pytest.raises(_lib.DepthwarpError):
         _lib.check(-3, "x")
 

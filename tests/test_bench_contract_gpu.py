@@ -27,5 +27,39 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["limits"][0]["bound"] == "hbm" and r["binding"] in ("hbm", "valu_issue")
+    assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_launches_two_ranks():
+    """`--gpus 2` with no launcher in the environment: two ranks are started.  On the one-GPU box
+    both share device 0 and the collectives run over gloo (rehearsal); the arithmetic of the line --
+    world size, global batch, whole-job frames/s -- is what is checked."""
+    env = {"DW_BENCH_REHEARSAL": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    d = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], env)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 24
+    assert abs(d["value"] - 3 * 24 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    d = _run(["--gpus", "2", "--mode", "dp", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["mode"] == "dp"
+    assert "all-reduce" in d["config"]["collective"]
+
+
+def test_train_mode_reports_the_share_of_the_loss_op():
+    d = _run(["--mode", "train", "--steps", "5", "--warmup", "2", "--net-width", "16"])
+    assert d["config"]["mode"] == "train" and d["n_gpus"] == 1 and d["config"]["global_batch"] == 12
+    assert 0 < d["loss_op_share"] < 1 and d["loss_op_ms"] > 0

@@ -29,6 +29,25 @@ def test_compute_loss_matches_oracle(B, Ht, Wt, H, W):
     assert out.dim() == (0 if B == 1 else 1)
 
 
+@pytest.mark.parametrize("B,Ht,Wt,H,W", [(1, 375, 1242, 256, 512), (2, 375, 1242, 192, 640), (2, 50, 70, 37, 45),
+                                          (1, 40, 60, 64, 128)])
+def test_antialiased_resize_matches_oracle(B, Ht, Wt, H, W):
+    """torchvision's `resize` (train.py:276) anti-aliases tensors in some releases and not in
+    others; both settings are compared with the oracle, at the reference's own 375x1242 -> 256x512,
+    and the two settings must differ when the target is shrunk (the test is not vacuous)."""
+    from oracle.compute_loss import compute_loss_terms as ref_terms
+    from depth_estimation_amd.loss import compute_loss_terms
+    target, pred = _inputs(B, Ht, Wt, H, W, seed=Ht + B)
+    plain = compute_loss_terms(target.cuda(), pred.cuda(), antialias=False)
+    for aa in (False, True):
+        ref = ref_terms(target, pred, antialias=aa)
+        got = compute_loss_terms(target.cuda(), pred.cuda(), antialias=aa)
+        for k in ("loss", "ssim_term", "l1", "smooth"):
+            assert torch.allclose(got[k].cpu(), ref[k], rtol=RTOL, atol=0), (aa, k, got[k], ref[k])
+    if Ht > H:
+        assert not torch.allclose(got["loss"], plain["loss"], rtol=1e-3, atol=0)
+
+
 def test_batched_equals_per_sample_loop():
     from depth_estimation_amd.loss import compute_loss
     target, pred = _inputs(4, 96, 320, 64, 128, seed=9)

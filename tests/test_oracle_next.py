@@ -30,7 +30,7 @@ def test_soft_argmin_closed_form():
     from oracle.soft_argmin import soft_argmin
     # constant cost: both soft-maxes are uniform, the result is the mean disparity index
     out = soft_argmin(torch.zeros(1, 8, 2, 3))
-    assert out.shape == (1, 1, 2, 3)
+    assert out.shape == (1, 2, 3)   # the reference's (1, H, W), model.py:428
     assert torch.allclose(out, torch.full_like(out, 3.5))
     # the second soft-max of a normalised volume flattens even a one-hot first soft-max
     c = torch.full((1, 4, 1, 1), 100.0)

@@ -36,8 +36,39 @@ def _hip(seq, upstream=1.0):
     return terms.detach().cpu(), mask.cpu(), [d.grad.cpu() for d in disp], T.grad.cpu()
 
 
-def _rel(a, b):
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+def _rel(a, b, keep=None):
+    e = (a - b).abs()
+    if keep is not None:
+        e = e * keep
+    return float(e.max() / b.abs().max().clamp_min(1e-30))
+
+
+def smoothness_ties(disp):
+    """Pixels of a disparity map (B,1,h,w) that touch a neighbour whose raw value differs while the
+    mean-normalised values agree to a few units in the last place.  The smoothness term takes |.| of
+    the normalised difference, which has no gradient at 0, and whether rounding puts such a
+    difference at 0 depends on the reduction order of the image mean: the oracle and the kernel may
+    pick different subgradients there.  Synthetic 3x3-smoothed maps hold such pairs about once per
+    hundred maps; the comparison leaves these pixels out and asserts that they are few."""
+    eps = torch.finfo(disp.dtype).eps
+    d = disp / (disp.mean(dim=(2, 3), keepdim=True) + 1e-7)
+    out = torch.zeros_like(disp, dtype=torch.bool)
+    tx = (disp[..., :, :-1] != disp[..., :, 1:]) & \
+        ((d[..., :, :-1] - d[..., :, 1:]).abs() <= 4 * eps * d[..., :, :-1].abs())
+    ty = (disp[..., :-1, :] != disp[..., 1:, :]) & \
+        ((d[..., :-1, :] - d[..., 1:, :]).abs() <= 4 * eps * d[..., :-1, :].abs())
+    out[..., :, :-1] |= tx
+    out[..., :, 1:] |= tx
+    out[..., :-1, :] |= ty
+    out[..., 1:, :] |= ty
+    return out
+
+
+def grad_disp_err(hip, ref, disp):
+    """Max-norm relative error of a disparity gradient outside the smoothness ties."""
+    ties = smoothness_ties(disp)
+    assert int(ties.sum()) <= max(4, disp.numel() // 1000), f"{int(ties.sum())} tie pixels"
+    return _rel(hip, ref, (~ties).to(ref.dtype))
 
 
 @pytest.mark.parametrize("B,H,W,tie", [(2, 24, 80, False), (2, 48, 160, False), (1, 64, 192, True),
@@ -53,7 +84,8 @@ def test_parity_small(B, H, W, tie):
         assert abs(float(terms[1 + s]) - float(aux["L_photo"][s])) <= LOSS_RTOL * float(aux["L_photo"][s])
         assert abs(float(terms[1 + S + s]) - float(aux["L_sm"][s])) <= LOSS_RTOL * float(aux["L_sm"][s])
     for s in range(S):
-        assert _rel(hgd[s], gd[s]) <= GRAD_RTOL, f"grad disp[{s}] rel err {_rel(hgd[s], gd[s])}"
+        e = grad_disp_err(hgd[s], gd[s], seq.disp[s])
+        assert e <= GRAD_RTOL, f"grad disp[{s}] rel err {e}"
     assert _rel(hgT[:, :, :3], gT[:, :, :3]) <= GRAD_RTOL, f"grad T rel err {_rel(hgT, gT)}"
     # all four candidates and both validity states occur: the test is not vacuous
     idx = masks & 3
@@ -68,8 +100,94 @@ def test_parity_full_resolution():
     assert torch.equal(mask, masks)
     assert abs(float(terms[0]) - float(loss)) <= LOSS_RTOL * abs(float(loss))
     for s in range(4):
-        assert _rel(hgd[s], gd[s]) <= GRAD_RTOL
+        assert grad_disp_err(hgd[s], gd[s], seq.disp[s]) <= GRAD_RTOL
     assert _rel(hgT[:, :, :3], gT[:, :, :3]) <= GRAD_RTOL
+
+
+def test_parity_high_resolution_forward_and_backward():
+    """One sample at 384x1280 (the high-resolution configuration), forward and backward against the oracle."""
+    _check_against_oracle(make_sequence(1, 384, 1280, seed=13))
+
+
+def test_batch_of_16_equals_per_sample_calls():
+    """The data-parallel shard (16 sequences at 192x640): every sample of the batched call must equal
+    the call on that sample alone -- masks bit for bit; the loss is the mean of the per-sample losses
+    and a per-sample gradient is 16 times its slice of the batched one (the loss is a batch mean)."""
+    from depth_estimation_amd.ops import PhotometricPlan
+    B, H, W = 16, 192, 640
+    seq = make_sequence(B, H, W, seed=16).to("cuda")
+    plan = PhotometricPlan(B, H, W, 4, "cuda").bind(*seq.args())
+    plan.forward(True)
+    plan.backward()
+    one = PhotometricPlan(1, H, W, 4, "cuda")
+    losses = []
+    for b in range(B):
+        sl = lambda t: t[b:b + 1].contiguous()
+        one.bind([sl(d) for d in seq.disp], [sl(c) for c in seq.color], [sl(c) for c in seq.color_pyr],
+                 sl(seq.K), sl(seq.inv_K), sl(seq.T))
+        one.forward(True)
+        one.backward()
+        assert torch.equal(one.mask[:, 0], plan.mask[:, b])
+        for s in range(4):
+            assert _rel(plan.grad_disp[s][b:b + 1] * B, one.grad_disp[s]) <= 2e-6
+        assert _rel(plan.grad_T[b:b + 1] * B, one.grad_T) <= 2e-6
+        losses.append(one.loss.clone())
+    # every term of the batched loss is the mean of the per-sample terms
+    assert torch.allclose(torch.stack(losses).mean(0), plan.loss, rtol=2e-6, atol=0)
+
+
+def test_per_scale_terms_are_differentiable():
+    """A loss built from the per-scale terms (not only the total) must get the gradient of that
+    combination: upstream gradients of all 1 + 2S outputs reach the kernels."""
+    from oracle import photometric as ph
+    from depth_estimation_amd import ops
+    seq = make_sequence(2, 32, 96, seed=31)
+    w = torch.tensor([0.5, 1.5, -0.25, 0.75, 2.0, 30.0, -10.0, 5.0, 80.0])
+    disp = [d.clone().requires_grad_(True) for d in seq.disp]
+    T = seq.T.clone().requires_grad_(True)
+    loss, aux = ph.photometric_stack(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T, return_aux=True)
+    # aux holds detached copies: rebuild the per-scale terms with a graph
+    S = 4
+    H, W = seq.color[0].shape[-2:]
+    rays = ph.pixel_rays(seq.inv_K, H, W)
+    P = [ph.proj_matrix(seq.K, T[:, f]) for f in range(2)]
+    ident = [ph.reprojection_error(seq.color[1 + f], seq.color[0]) for f in range(2)]
+    combo = w[0] * loss
+    for s in range(S):
+        up = ph.upsample_bilinear(disp[s], H, W)
+        depth = ph.disp_to_depth(up)[1][:, 0]
+        rp = []
+        for f in range(2):
+            _, _, gx, gy, _ = ph.project(depth, rays, P[f], H, W)
+            rp.append(ph.reprojection_error(ph.warp_bilinear(seq.color[1 + f], gx, gy), seq.color[0]))
+        m, _, _ = ph.min_first(ident + rp)
+        combo = combo + w[1 + s] * m.mean() + w[1 + S + s] * ph.smooth_loss(disp[s], seq.color_pyr[s])
+    combo.backward()
+    g = seq.to("cuda")
+    hd = [d.clone().requires_grad_(True) for d in g.disp]
+    hT = g.T.clone().requires_grad_(True)
+    terms, _ = ops.photometric_forward(hd, g.color, g.color_pyr, g.K, g.inv_K, hT)
+    (terms * w.cuda()).sum().backward()
+    for s in range(S):
+        assert grad_disp_err(hd[s].grad.cpu(), disp[s].grad, seq.disp[s]) <= GRAD_RTOL
+    assert _rel(hT.grad.cpu()[:, :, :3], T.grad[:, :, :3]) <= GRAD_RTOL
+    # and a single per-scale term alone
+    hd2 = [d.clone().requires_grad_(True) for d in g.disp]
+    terms2, _ = ops.photometric_forward(hd2, g.color, g.color_pyr, g.K, g.inv_K, g.T)
+    terms2[1 + 2].backward()
+    assert float(hd2[2].grad.abs().max()) > 0 and float(hd2[0].grad.abs().max()) == 0
+
+
+def test_plan_on_an_explicit_device_and_shape_limit():
+    from depth_estimation_amd import _lib
+    from depth_estimation_amd.ops import PhotometricPlan
+    seq = make_sequence(1, 32, 96, seed=2).to("cuda:0")
+    plan = PhotometricPlan(1, 32, 96, 4, torch.device("cuda", 0)).bind(*seq.args())
+    plan.forward(True)
+    plan.backward()
+    assert torch.isfinite(plan.loss).all()
+    # H * W beyond 2^28 is refused before anything is launched
+    assert _lib.lib().dw_photometric_workspace_bytes(_lib.DwDesc(1, 16384, 16392, 4, 2, 0)) == 0
 
 
 def test_upstream_gradient_scales():
@@ -172,7 +290,8 @@ def _check_against_oracle(seq):
     assert torch.equal(mask, masks), f"mask mismatch at {int((mask != masks).sum())} pixels"
     assert abs(float(terms[0]) - float(loss)) <= LOSS_RTOL * abs(float(loss))
     for s in range(S):
-        assert _rel(hgd[s], gd[s]) <= GRAD_RTOL, f"grad disp[{s}] rel err {_rel(hgd[s], gd[s])}"
+        e = grad_disp_err(hgd[s], gd[s], seq.disp[s])
+        assert e <= GRAD_RTOL, f"grad disp[{s}] rel err {e}"
     if float(gT.abs().max()) > 0:
         assert _rel(hgT[:, :, :3], gT[:, :, :3]) <= GRAD_RTOL
     return masks

@@ -24,7 +24,7 @@ def test_matches_reference_lines(B, D, H, W, scale):
     gc = cost.detach().cuda().requires_grad_(True)
     got = soft_argmin(gc)
     (got * w.cuda()).sum().backward()
-    assert got.shape == (B, 1, H, W)
+    assert got.shape == want.shape == (B, H, W)
     assert torch.allclose(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-6)
     if D > 1:
         assert _rel(gc.grad.cpu(), cost.grad) <= 1e-4
@@ -40,6 +40,8 @@ def test_reference_call_shape_and_peaked_volume():
     idx = torch.randint(0, D, (H, W), generator=torch.Generator().manual_seed(0))
     cost[0].scatter_(0, idx[None], -50.0)
     got = soft_argmin(cost.cuda()).cpu()
+    # the reference's own call shape: (1, 256, H, W) in, (1, H, W) out (model.py:428)
+    assert got.shape == ref(cost).shape == (1, H, W)
     assert torch.allclose(got, ref(cost), rtol=1e-5)
     assert float((got - (D - 1) / 2).abs().max()) < 2.0
 
