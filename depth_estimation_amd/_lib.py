@@ -20,6 +20,7 @@ DW_FLAG_TILE_KERNEL_ONLY = 1
 DW_FLAG_NO_TAIL_SPLIT = 2
 DW_FLAG_COLOR_GRAD = 4
 DW_CL_FLAG_ANTIALIAS = 1
+DW_STATIC_SCRATCH_BYTES = 1 << 20
 
 
 class DwDesc(C.Structure):
@@ -46,6 +47,7 @@ _SIGNATURES = {
     "dw_photometric_bwd_color": (C.c_int, [C.POINTER(DwDesc), _VP, _VP, C.c_size_t, _PP, _VP]),
     "dw_compute_loss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dw_compute_loss_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
+    "dw_compute_loss_fwd_static": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, C.c_int32, _VP]),
     "dw_compute_loss_metrics_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, C.c_float, C.c_float, _VP, C.c_int32,
                                                             _VP, C.c_size_t, _VP]),
     "dw_normalize_image_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),

@@ -11,6 +11,9 @@ extern "C" const char* dw_strerror(int code) {
     case DW_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
     case DW_ERR_LAUNCH: return "kernel launch failed";
     case DW_ERR_ARG: return "bad flag or enum value";
+    case DW_ERR_TOO_LARGE:
+      return "problem too large for the fixed scratch array of the allocation-free entry point "
+             "(use the variant that takes a workspace)";
     default: return "unknown error code";
   }
 }

@@ -20,6 +20,8 @@
 //   rmse = sqrt(mean((resize(gt) - clamp(1/pred, lo, hi))^2))    train.py:311-343
 //   min(pred), max(pred) for normalize_image                     train.py:248-253
 // and normalize_image itself is the element-wise kernel at the end of the file.
+#include <mutex>
+
 #include "dw_common.h"
 
 namespace dw {
@@ -433,6 +435,50 @@ extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, in
   if (!(clamp_min <= clamp_max)) return DW_ERR_ARG;
   return compute_loss_launch<true>(B, Ht, Wt, H, W, target, pred, clamp_min, clamp_max, out, flags, workspace,
                                    workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------- allocation-free entry point
+// The per-tile partial sums of dw_compute_loss_fwd live in a fixed device array
+// of this library instead of a caller workspace.  Every GPU the library runs on
+// holds its own copy of the array at its own address until the process ends;
+// `scratch` itself is only a host-side handle of the symbol (not a device
+// address), so the address on the current device is looked up once per device
+// and that pointer is what the kernels receive.
+static __device__ __align__(256) unsigned char scratch[DW_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of `scratch` on the current device (nullptr on failure).
+void* static_scratch_ptr() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess) return nullptr;
+    g_scratch_ptr[dev] = ptr;
+  }
+  return g_scratch_ptr[dev];
+}
+}  // namespace
+
+extern "C" int dw_compute_loss_fwd_static(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                                          const float* target, const float* pred, float* out, int32_t flags,
+                                          void* stream) {
+  if (!target || !pred || !out) return DW_ERR_NULL;
+  if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
+  const size_t need = dw_compute_loss_workspace_bytes(B, H, W);
+  if (need == 0) return DW_ERR_SHAPE;
+  if (need > DW_STATIC_SCRATCH_BYTES) return DW_ERR_TOO_LARGE;
+  void* ptr = static_scratch_ptr();
+  if (!ptr) return DW_ERR_LAUNCH;
+  // every partial the finalisation reads is written by the tile kernel of the same call:
+  // nothing in the array has to start at zero
+  return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, flags, ptr,
+                                    DW_STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" size_t dw_normalize_image_workspace_bytes(int32_t B, int64_t n) {

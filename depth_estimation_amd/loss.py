@@ -17,7 +17,7 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["compute_loss", "compute_loss_terms"]
+__all__ = ["compute_loss", "compute_loss_terms", "compute_loss_into"]
 
 
 def _as_b1hw(name: str, t: Tensor) -> Tensor:
@@ -85,3 +85,29 @@ def compute_loss(target: Tensor, pred: Tensor, height: int = None, width: int = 
     (`F.interpolate(..., antialias=True)`)."""
     loss = compute_loss_terms(target, pred, height, width, antialias)["loss"]
     return loss[0] if loss.numel() == 1 else loss
+
+
+def compute_loss_into(out: Tensor, target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
+    """`compute_loss_terms` for callers that must not allocate (a loop under HIP graph capture,
+    a harness that forbids device allocation): the caller passes the result buffer `out` (B, 4)
+    float32 -- loss, ssim_term, l1, smooth per sample -- and the library uses its own fixed scratch
+    array for the partial sums (`dw_compute_loss_fwd_static`).  Inputs must already be float32,
+    contiguous (B,1,Ht,Wt) / (B,1,H,W) device tensors: nothing is converted or copied here.
+    Problems beyond the scratch array's size raise; calls that overlap on one GPU race."""
+    for name, t in (("out", out), ("target", target), ("pred", pred)):
+        if not t.is_cuda:
+            raise _lib.DepthwarpError(f"compute_loss_into: {name} must be a ROCm device tensor")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"compute_loss_into: {name} must be contiguous float32")
+    if pred.dim() != 4 or target.dim() != 4 or pred.shape[1] != 1 or target.shape[1] != 1:
+        raise RuntimeError("compute_loss_into: expected target (B,1,Ht,Wt) and pred (B,1,H,W)")
+    B, _, H, W = pred.shape
+    if target.shape[0] != B or tuple(out.shape) != (B, 4):
+        raise RuntimeError("compute_loss_into: target, pred and out (B,4) disagree on the batch size")
+    with torch.cuda.device(pred.device):
+        rc = _lib.lib().dw_compute_loss_fwd_static(B, target.shape[2], target.shape[3], H, W, target.data_ptr(),
+                                                   pred.data_ptr(), out.data_ptr(),
+                                                   _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0,
+                                                   torch.cuda.current_stream(pred.device).cuda_stream)
+    _lib.check(rc, "dw_compute_loss_fwd_static")
+    return out

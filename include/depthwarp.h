@@ -47,7 +47,8 @@ enum {
   DW_ERR_SHAPE = -2,     /* unsupported or inconsistent dimensions             */
   DW_ERR_WORKSPACE = -3, /* workspace too small or misaligned                  */
   DW_ERR_LAUNCH = -4,    /* hipLaunchKernel / hipGetLastError reported failure */
-  DW_ERR_ARG = -5        /* bad flag or enum value                             */
+  DW_ERR_ARG = -5,       /* bad flag or enum value                             */
+  DW_ERR_TOO_LARGE = -6  /* problem exceeds the fixed scratch of an allocation-free entry point */
 };
 
 /* Problem description of the photometric stack. Scale s has H>>s x W>>s
@@ -170,6 +171,24 @@ DW_API size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
 DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
                         const float* target, const float* pred, float* out, int32_t flags,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* dw_compute_loss_fwd for callers that cannot allocate or bring a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference; same kernels and results as
+ * dw_compute_loss_fwd.  The per-tile partial sums live in a fixed device array
+ * inside the library (DW_STATIC_SCRATCH_BYTES per GPU the library runs on, held
+ * until the process ends); the call allocates and frees nothing.
+ *   - the problem must fit: dw_compute_loss_workspace_bytes(B, H, W) <=
+ *     DW_STATIC_SCRATCH_BYTES (e.g. B <= 256 at 256 x 512), else DW_ERR_TOO_LARGE;
+ *   - all calls on one GPU share that GPU's array: calls that overlap in time on
+ *     one GPU (different streams or threads) race -- serialise them, or use
+ *     dw_compute_loss_fwd with workspaces of their own;
+ *   - the array's address is looked up on the first call on each device: make
+ *     that first call outside stream capture. */
+#define DW_STATIC_SCRATCH_BYTES (1u << 20)
+DW_API int dw_compute_loss_fwd_static(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                               const float* target, const float* pred, float* out, int32_t flags,
+                               void* stream);
 
 /* The same pass, additionally producing the evaluation metrics the reference
  * computes from the same two tensors: Train.compute_errors /

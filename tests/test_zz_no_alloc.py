@@ -1,0 +1,76 @@
+"""The allocation-free entry point dw_compute_loss_fwd_static (fixed scratch array inside the
+library) against dw_compute_loss_fwd (caller workspace): same kernels, so the results must be
+bit-identical -- on two calls in a row, the second with a smaller input, which also shows that
+what the first call left in the shared array does not leak into the second."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_workspace(lib, target, pred, flags):
+    B, _, H, W = pred.shape
+    n = lib.dw_compute_loss_workspace_bytes(B, H, W)
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = torch.full((B, 4), float("nan"), device="cuda")
+    rc = lib.dw_compute_loss_fwd(B, target.shape[2], target.shape[3], H, W, target.data_ptr(), pred.data_ptr(),
+                                 out.data_ptr(), flags, ws.data_ptr(), n,
+                                 torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return out
+
+
+def _static(lib, target, pred, flags):
+    B, _, H, W = pred.shape
+    out = torch.full((B, 4), float("nan"), device="cuda")
+    rc = lib.dw_compute_loss_fwd_static(B, target.shape[2], target.shape[3], H, W, target.data_ptr(),
+                                        pred.data_ptr(), out.data_ptr(), flags,
+                                        torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.dw_strerror(rc)
+    return out
+
+
+def test_static_scratch_entry_point_matches_the_workspace_one_twice_in_a_row():
+    from depth_estimation_amd import _lib
+    from oracle.compute_loss import compute_loss_terms as ref_terms
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    cases = [((3, 1, 375, 1242), (3, 1, 256, 512), 0),      # the reference's own sizes, batched
+             ((1, 1, 50, 70), (1, 1, 37, 45), _lib.DW_CL_FLAG_ANTIALIAS)]   # then a smaller problem
+    for tshape, pshape, flags in cases:
+        target = torch.rand(*tshape, generator=g).cuda()
+        pred = torch.rand(*pshape, generator=g).cuda()
+        want = _with_workspace(lib, target, pred, flags)
+        got = _static(lib, target, pred, flags)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, want), (got, want)
+        # and both agree with the CPU restatement (1e-5 relative)
+        ref = ref_terms(target.cpu(), pred.cpu(), antialias=bool(flags))
+        for i, k in enumerate(("loss", "ssim_term", "l1", "smooth")):
+            assert torch.allclose(got[:, i].cpu(), ref[k], rtol=1e-5, atol=0), k
+
+
+def test_static_scratch_entry_point_refuses_what_does_not_fit_and_python_wrapper():
+    from depth_estimation_amd import _lib
+    from depth_estimation_amd.loss import compute_loss_into, compute_loss_terms
+    lib = _lib.lib()
+    # 8 floats per 16 x 64 tile and sample: 2048 x 2048 at B = 16 needs 2 MiB of partials
+    B, H, W = 16, 2048, 2048
+    assert lib.dw_compute_loss_workspace_bytes(B, H, W) > _lib.DW_STATIC_SCRATCH_BYTES
+    x = torch.zeros(1, device="cuda")
+    rc = lib.dw_compute_loss_fwd_static(B, H, W, H, W, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, None)
+    assert rc == -6 and b"too large" in lib.dw_strerror(rc)
+    assert lib.dw_compute_loss_fwd_static(1, 8, 8, 8, 8, None, None, None, 0, None) == -1
+    assert lib.dw_compute_loss_fwd_static(1, 8, 8, 8, 8, x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, None) == -5
+    g = torch.Generator().manual_seed(1)
+    target, pred = torch.rand(2, 1, 96, 320, generator=g).cuda(), torch.rand(2, 1, 64, 128, generator=g).cuda()
+    out = torch.empty(2, 4, device="cuda")
+    compute_loss_into(out, target, pred)
+    want = compute_loss_terms(target, pred)
+    assert torch.equal(out[:, 0], want["loss"]) and torch.equal(out[:, 3], want["smooth"])
+    with pytest.raises(_lib.DepthwarpError):
+        compute_loss_into(torch.empty(B, 4, device="cuda"), torch.zeros(B, 1, H, W, device="cuda"),
+                          torch.zeros(B, 1, H, W, device="cuda"))
