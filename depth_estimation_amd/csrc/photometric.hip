@@ -1587,14 +1587,19 @@ __device__ __forceinline__ void grad_pose_block(const BwdParams& p, int b) {
     const int g = tid / 24, k = tid - g * 24;
     double a = 0.0;
     const float* src = p.tile_dP + (long)b * nrow * 24 + k;
-    int sc = g % p.S;  // row t belongs to scale t % S
-    const int step = GP_GROUPS % p.S;
+    if (p.g_len > 1) {
+      int sc = g % p.S;  // row t belongs to scale t % S
+      const int step = GP_GROUPS % p.S;
 #pragma unroll 8
-    for (int t = g; t < nrow; t += GP_GROUPS) {
-      const double w = (sc == 0) ? wsc[0] : (sc == 1) ? wsc[1] : (sc == 2) ? wsc[2] : wsc[3];
-      a += w * (double)src[(long)t * 24];
-      sc += step;
-      sc -= (sc >= p.S) ? p.S : 0;
+      for (int t = g; t < nrow; t += GP_GROUPS) {
+        const double w = (sc == 0) ? wsc[0] : (sc == 1) ? wsc[1] : (sc == 2) ? wsc[2] : wsc[3];
+        a += w * (double)src[(long)t * 24];
+        sc += step;
+        sc -= (sc >= p.S) ? p.S : 0;
+      }
+    } else {
+#pragma unroll 8
+      for (int t = g; t < nrow; t += GP_GROUPS) a += (double)src[(long)t * 24];
     }
     s_part[g][k] = a;
   }

@@ -190,6 +190,45 @@ def test_plan_on_an_explicit_device_and_shape_limit():
     assert _lib.lib().dw_photometric_workspace_bytes(_lib.DwDesc(1, 16384, 16392, 4, 2, 0)) == 0
 
 
+def sweep_case(seed, B, H, W):
+    """Case `seed` of tools/parity_sweep.py: odd seeds push part of the samples over the image border
+    or behind the camera with translations that grow with the seed."""
+    seq = make_sequence(B, H, W, seed=1000 + seed, tie_noise=(seed % 3 == 0))
+    if seed % 2:
+        T = seq.T.clone()
+        g = torch.Generator().manual_seed(seed)
+        T[:, :, :3, 3] += torch.randn(B, 2, 3, generator=g) * (0.5 * seed)
+        seq.T = T
+    return seq
+
+
+def test_parity_sweep_outlier_ill_conditioned_pose():
+    """The one case in 300 of the seed sweep (`profiles/r02_parity_sweep.json`) whose disparity
+    gradient differs from the float32 oracle by more than 1e-4 (2.1e-4 at one coarse-scale pixel).
+    Its pose makes the projection adjoint cancel: the float32 oracle itself is up to 1.6e-2 away
+    from the same oracle evaluated in float64.  Checked here against the float64 evaluation: the
+    kernel must be no further from it than twice the float32 oracle is (plus the 1e-4 bar), with
+    masks still bit-exact against the float32 oracle."""
+    seq = sweep_case(3, 1, 48, 160)
+    loss, aux, masks, gd32, gT32 = _oracle(seq)
+    _, _, _, gd64, gT64 = _oracle(seq.to("cpu", torch.float64))
+    terms, mask, hgd, hgT = _hip(seq)
+    assert torch.equal(mask, masks)
+    assert abs(float(terms[0]) - float(loss)) <= LOSS_RTOL * abs(float(loss))
+    worst_vs_f32 = 0.0
+    for s in range(4):
+        ties = (~smoothness_ties(seq.disp[s])).double()
+        scale = gd64[s].abs().max()
+        e_hip = float(((hgd[s].double() - gd64[s]).abs() * ties).max() / scale)
+        e_f32 = float(((gd32[s].double() - gd64[s]).abs() * ties).max() / scale)
+        assert e_hip <= 2 * e_f32 + GRAD_RTOL, (s, e_hip, e_f32)
+        worst_vs_f32 = max(worst_vs_f32, grad_disp_err(hgd[s], gd32[s], seq.disp[s]))
+    # documented size of the miss against the float32 oracle (it is an outlier, not a regression)
+    assert worst_vs_f32 <= 5e-4
+    e_hip = _rel(hgT[:, :, :3].double(), gT64[:, :, :3])
+    assert e_hip <= 2 * _rel(gT32[:, :, :3].double(), gT64[:, :, :3]) + GRAD_RTOL
+
+
 def test_upstream_gradient_scales():
     seq = make_sequence(1, 32, 128, seed=3)
     _, _, gd1, gT1 = _hip(seq, 1.0)

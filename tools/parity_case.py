@@ -6,10 +6,8 @@ from depth_estimation_amd import ops
 from depth_estimation_amd.synth import make_sequence
 from oracle import photometric as ph
 seed, B, H, W = (int(v) for v in sys.argv[1:5])
-seq = make_sequence(B, H, W, seed=1000 + seed, tie_noise=(seed % 3 == 0))
-if seed % 2:
-    T = seq.T.clone(); g = torch.Generator().manual_seed(seed)
-    T[:, :, :3, 3] += torch.randn(B, 2, 3, generator=g) * (0.5 * seed); seq.T = T
+from tests.test_photometric_gpu import sweep_case
+seq = sweep_case(seed, B, H, W)
 disp = [d.clone().requires_grad_(True) for d in seq.disp]
 T = seq.T.clone().requires_grad_(True)
 loss = ph.photometric_stack(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T, seq.tie_noise)

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from depth_estimation_amd import ops  # noqa: E402
 from depth_estimation_amd.synth import make_sequence  # noqa: E402
 from oracle import photometric as ph  # noqa: E402
-from tests.test_photometric_gpu import smoothness_ties  # noqa: E402
+from tests.test_photometric_gpu import smoothness_ties, sweep_case  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 bad = 0
@@ -22,12 +22,7 @@ n_ties = 0
 worst = [0.0, 0.0, 0.0]
 for seed in range(n):
     for B, H, W in ((2, 32, 96), (1, 48, 160), (1, 40, 104)):
-        seq = make_sequence(B, H, W, seed=1000 + seed, tie_noise=(seed % 3 == 0))
-        if seed % 2:  # push part of the samples over the image border / behind the camera
-            T = seq.T.clone()
-            g = torch.Generator().manual_seed(seed)
-            T[:, :, :3, 3] += torch.randn(B, 2, 3, generator=g) * (0.5 * seed)
-            seq.T = T
+        seq = sweep_case(seed, B, H, W)
         disp = [d.clone().requires_grad_(True) for d in seq.disp]
         T = seq.T.clone().requires_grad_(True)
         loss, aux = ph.photometric_stack(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T, seq.tie_noise,
