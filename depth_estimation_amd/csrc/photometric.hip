@@ -21,9 +21,14 @@
 // adds the smoothness term and scales by the upstream gradient.  No
 // floating-point atomics anywhere: results are bitwise reproducible.  The
 // optional gradient with respect to the warped source images (flag
-// DW_FLAG_COLOR_GRAD, photo_tile_color_kernel) is a scatter; it accumulates in
-// 64-bit fixed point with integer atomics, which is independent of the order
-// of the additions and therefore reproducible as well.
+// DW_FLAG_COLOR_GRAD) is a scatter: photo_tile_color_kernel also stores the
+// per-pixel adjoint of the warped colours, color_scatter_kernel accumulates the
+// four-tap scatter of a tile in an LDS patch per source frame (64-bit fixed
+// point, so the order of the additions does not matter) and writes the patch to
+// a slot of its own with plain stores, and grad_color_kernel sums, per source
+// pixel, the slots that cover it in a fixed order.  Only samples that leave
+// their tile's patch (extreme poses) fall back to integer atomics in global
+// memory.
 //
 // Tile geometry.  A block owns an "error-map region" Q of QH x QW pixels, one
 // 1xSW strip per thread (NT = QH * QW/SW threads).  The colour / warped region R is
@@ -110,7 +115,7 @@ struct PhotoParams {
   float* tile_loss;  // [B][tiles][4]
   float* tile_dP;    // [B][tiles][S][24]
   float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
-  unsigned long long* gcol;  // [2][B][3][H][W]  d loss / d (warped source image), 2^-32 fixed point; optional
+  float* gxout;      // [S][B][2][3][H][W]      d loss / d (warped colour of frame f), unit upstream; optional
   float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
   float* sm_part;    // [blk_off[S]][4]         per block: smoothness sums x, y; sum G * disp; sum disp
@@ -204,6 +209,7 @@ struct SampleAddr {
   // element of the pair and the fraction is 0; the blend then runs with tx = 1,
   // which gives the first element weight 0 and the same sums (x * 0 + y = y).
   unsigned o_n, o_s;
+  int x0, y0, x1, y1;               // integer coordinates of the four taps
   float tx, ty;                     // fractional position inside the pair / cell
   // status bits of the sample, already at their place in the region's status byte
   // for source frame f: bit 2 + f inside the image before clamping and in front of
@@ -259,6 +265,7 @@ __device__ __forceinline__ void sample_addr(int H, int W, const DivConsts& dc, c
   a.ty = iy - iy0;
   const int x0 = (int)ix0, y0 = (int)iy0;
   const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  a.x0 = x0, a.y0 = y0, a.x1 = x1, a.y1 = y1;
   a.o_nw = (unsigned)(y0 * W + x0) * 4u;
   a.o_ne = (unsigned)(y0 * W + x1) * 4u;
   a.o_sw = (unsigned)(y1 * W + x0) * 4u;
@@ -381,14 +388,8 @@ __device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
 #endif
 
 // ------------------------------------------------------------ the tile kernel
-// One contribution to a fixed-point sum: 2^-32 units, integer addition.
-__device__ __forceinline__ void atomic_add_fixed(unsigned long long* dst, float v) {
-  const long long q = (long long)(v * 4294967296.0f);
-  __hip_atomic_fetch_add(dst, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// GRAD: with the per-pixel backward.  CGRAD (needs GRAD): also scatter the
-// gradient with respect to the two warped source images into p.gcol.
+// GRAD: with the per-pixel backward.  CGRAD (needs GRAD): also store the
+// adjoint of the warped colours of both frames into p.gxout.
 template <bool GRAD, bool CGRAD>
 __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
   using Gm = Geom<GRAD>;
@@ -981,17 +982,6 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int q = 0; q < SW; ++q) gix[f][q] = giy[f][q] = 0.f;
-        // where the pixel samples each source frame: the forward arithmetic again,
-        // bit for bit (same depth, same ray, same projection matrix)
-        SampleAddr ca[CGRAD ? 2 : 1][SW];
-        if (CGRAD) {
-#pragma unroll
-          for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int q = 0; q < SW; ++q)
-              sample_addr<false>(H, W, dc, f ? P1 : P0, depth[q] * r0[q], depth[q] * r1[q], depth[q] * r2[q],
-                                 (unsigned)f, ca[CGRAD ? f : 0][q]);
-        }
         // weights of the frame-0 neighbours (row weight times mask), shared by the nine planes
         float w0[3][WW];
 #pragma unroll
@@ -1074,16 +1064,11 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
               gix[f][q] = fmaf(gx, st[(c + 3) * QH * QW], gix[f][q]);
               giy[f][q] = fmaf(gx, st[(c + 6) * QH * QW], giy[f][q]);
               if (CGRAD) {
-                // adjoint of the bilinear blend: gx goes to the four taps with their weights
-                if (live[q] && any[f][q]) {
-                  const SampleAddr& a = ca[CGRAD ? f : 0][q];
-                  unsigned long long* gc = p.gcol + (((long)f * p.B + b) * 3 + c) * plane;
-                  const float ex = 1.0f - a.tx, ey = 1.0f - a.ty;
-                  atomic_add_fixed(gc + (a.o_nw >> 2), gx * (ex * ey));
-                  atomic_add_fixed(gc + (a.o_ne >> 2), gx * (a.tx * ey));
-                  atomic_add_fixed(gc + (a.o_sw >> 2), gx * (ex * a.ty));
-                  atomic_add_fixed(gc + (a.o_se >> 2), gx * (a.tx * a.ty));
-                }
+                // adjoint of the warped colour itself, for the scatter to the source image
+                const int x = sx_img + q, qc = SW * ql + q;
+                if (qc >= CO && qc < QW - CO && x < W)
+                  p.gxout[((((long)s * p.B + b) * 2 + f) * 3 + c) * plane + (long)sy_img * W + x] =
+                      (live[q] && any[f][q]) ? gx : 0.f;
               }
             }
           }
@@ -1631,25 +1616,241 @@ __global__ __launch_bounds__(SM_NT) void backward_kernel(const BwdParams p) {
 }
 
 // ------------------------------------------------- backward: d loss / d (warped sources)
-// Fixed-point sums of the tile kernel -> float gradients, scaled by the upstream
-// gradient and the 1 / (S * B * H * W) of the mean.
-__global__ __launch_bounds__(SM_NT) void grad_color_kernel(const long long* __restrict__ gcol,
-                                                           const float* __restrict__ grad_loss, float inv_count,
-                                                           float* __restrict__ out0, float* __restrict__ out1,
-                                                           long n_frame) {
+// The adjoint of the bilinear warp with respect to the image it samples is a
+// scatter: target pixel t adds gx(t) * w_tap to its four taps.  A block takes a
+// CS_TH x CS_TW tile of target pixels and one source frame and accumulates their
+// contributions, for every scale, into a CS_PH x CS_PW patch in LDS.  The patch
+// is anchored where the tile's centre pixel samples the frame (scale 0), so for
+// ordinary motion every tap of the tile falls inside it; the sums are 64-bit
+// fixed point (2^-32 units), which makes them independent of the order in which
+// the lanes arrive.  The patch then goes to a slot of its own in the workspace
+// with plain stores, and grad_color_kernel adds up, per source pixel, the slots
+// whose patches cover it, in tile order.  A tap outside the patch (a pose that
+// tears the tile's samples apart) is added to a dense fixed-point image in
+// global memory with an integer atomic instead -- the rare path.
+constexpr int CS_TH = 16, CS_TW = 32, CS_NT = 256;
+constexpr int CS_PH = 32, CS_PW = 48;
+constexpr int CS_MY = (CS_PH - CS_TH - 1) / 2, CS_MX = (CS_PW - CS_TW - 1) / 2;  // margin around the tile's own taps
+constexpr int CS_OFF_MAX = 16;  // largest displacement of a patch from its tile; bounds the search in grad_color_kernel
+
+struct ColorParams {
+  int B, H, W, S;
+  int tilesX, tilesY;
+  const float* disp[DW_MAX_SCALES];
+  const float* K;
+  const float* invK;
+  const float* T;
+  const float* gxout;         // [S][B][2][3][H][W]
+  unsigned long long* gcol;   // [2][B][3][H][W]   fixed-point sums of the taps outside their patch
+  float* slots;               // [B][tiles][2][3][CS_PH][CS_PW]
+  int* anchors;               // [B][tiles][2][2]  (row, column) of patch element (0, 0) in the source image
+  unsigned* spill_flag;       // set when any tap went to gcol
+};
+
+// v in 2^-32 units, rounded towards minus infinity: floor(v) in the upper word, the fraction
+// (exact: v - floor(v) has no rounding below 2^24) scaled by 2^32 in the lower one.  |v| < 2^31.
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+  const float hi = floorf(v);
+  const unsigned lo = (unsigned)((v - hi) * 4294967296.0f);
+  return ((unsigned long long)(unsigned)(int)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorParams p) {
+  // one block per (sample, tile, source frame): a 37 KB patch, three blocks per CU
+  __shared__ unsigned long long s_patch[3][CS_PH * CS_PW];
+  __shared__ __attribute__((aligned(16))) float s_P[12];
+  __shared__ float s_invK[9];
+  __shared__ int s_anchor[2];
+  __shared__ unsigned short s_queue[CS_TH * CS_TW * DW_MAX_SCALES];  // (pixel of the tile << 2) | scale
+  __shared__ int s_count;
+  const int tid = threadIdx.x;
+  const int ntile = p.tilesX * p.tilesY;
+  const int f = blockIdx.x & 1;
+  const int bt = blockIdx.x >> 1;  // (sample, tile): the slot index
+  const int b = bt / ntile, tile = bt - b * ntile;
+  const int tY = tile / p.tilesX, tX = tile - tY * p.tilesX;
+  const int ty0 = tY * CS_TH, tx0 = tX * CS_TW;
+  const int H = p.H, W = p.W;
+  const long plane = (long)H * W;
+  if (tid < 12) {  // the projection matrix, with the arithmetic of the forward pass
+    const int i = tid >> 2, j = tid & 3;
+    const float* Kb = p.K + (long)b * 16;
+    const float* Tb = p.T + ((long)b * DW_NUM_SRC + f) * 16;
+    s_P[tid] = ((Kb[i * 4 + 0] * Tb[0 * 4 + j] + Kb[i * 4 + 1] * Tb[1 * 4 + j]) + Kb[i * 4 + 2] * Tb[2 * 4 + j]) +
+               Kb[i * 4 + 3] * Tb[3 * 4 + j];
+  } else if (tid >= 16 && tid < 25) {
+    const int k = tid - 16;
+    s_invK[k] = p.invK[(long)b * 16 + (k / 3) * 4 + (k % 3)];
+  }
+  if (tid == 0) s_count = 0;
+  for (int i = tid; i < 3 * CS_PH * CS_PW; i += CS_NT) (&s_patch[0][0])[i] = 0ull;
+  // Only pixels that carry a gradient into this frame do any work (elsewhere the adjoint is an
+  // exact zero): they are queued first, for all scales at once, so that the heavy part runs on
+  // full waves and behind a single round of loads.  The order of the queue varies from run to
+  // run; the fixed-point sums do not depend on it.
+  const int lane = tid & (kWave - 1);
+  {
+    constexpr int NK = CS_TH * CS_TW / CS_NT;
+    bool live[DW_MAX_SCALES][NK];
+#pragma unroll
+    for (int s = 0; s < DW_MAX_SCALES; ++s) {
+      const int sc = s < p.S ? s : 0;
+      const float* gs = p.gxout + ((((long)sc * p.B + b) * 2 + f) * 3) * plane;
+#pragma unroll
+      for (int it = 0; it < NK; ++it) {
+        const int k = tid + it * CS_NT;
+        const int y = ty0 + k / CS_TW, x = tx0 + k % CS_TW;
+        const bool in_img = y < H && x < W;
+        const float* g = gs + (in_img ? (long)y * W + x : 0);
+        live[s][it] = s < p.S && in_img && (g[0] != 0.f || g[plane] != 0.f || g[2 * plane] != 0.f);
+      }
+    }
+    __syncthreads();  // s_count, the patch and the matrices are set
+#pragma unroll
+    for (int s = 0; s < DW_MAX_SCALES; ++s)
+#pragma unroll
+      for (int it = 0; it < NK; ++it) {
+        const unsigned long long m = __ballot(live[s][it]);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_count, __popcll(m));
+        base = __shfl(base, 0, kWave);
+        if (live[s][it])
+          s_queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(((tid + it * CS_NT) << 2) | s);
+      }
+  }
+  DivConsts dc;
+  dc.yw = div_rcp((float)(W - 1));
+  dc.yh = div_rcp((float)(H - 1));
+  // where target pixel (y, x) samples the frame at scale s: the forward arithmetic, bit for bit
+  auto sample_at = [&](int s, int y, int x, SampleAddr& a) __attribute__((always_inline)) {
+    const int hs = H >> s, ws = W >> s;
+    const float du = upsampled_disp(p.disp[s] + (long)b * hs * ws, hs, ws, s, y, x, (float)hs / (float)H,
+                                    (float)ws / (float)W);
+    const float dsp = kMinDisp + kDispRange * du;
+    const float depth = div_by(1.0f, dsp, div_rcp(dsp));
+    const float fx = (float)x, fy = (float)y;
+    const float X = depth * ((s_invK[0] * fx + s_invK[1] * fy) + s_invK[2]);
+    const float Y = depth * ((s_invK[3] * fx + s_invK[4] * fy) + s_invK[5]);
+    const float Z = depth * ((s_invK[6] * fx + s_invK[7] * fy) + s_invK[8]);
+    sample_addr<false>(H, W, dc, s_P, X, Y, Z, (unsigned)f, a);
+  };
+  if (tid == 0) {
+    // the patch is anchored where the tile's centre pixel samples the frame at scale 0
+    const int cy = min(ty0 + CS_TH / 2, H - 1), cx = min(tx0 + CS_TW / 2, W - 1);
+    SampleAddr a;
+    sample_at(0, cy, cx, a);
+    const int dy = min(max(a.y0 - cy, -CS_OFF_MAX), CS_OFF_MAX);
+    const int dx = min(max(a.x0 - cx, -CS_OFF_MAX), CS_OFF_MAX);
+    s_anchor[0] = ty0 + dy - CS_MY;
+    s_anchor[1] = tx0 + dx - CS_MX;
+  }
+  __syncthreads();
+  const int oy = s_anchor[0], ox = s_anchor[1];
+  const int n_items = s_count;
+  bool spilled = false;
+#pragma unroll 1
+  for (int i = tid; i < n_items; i += CS_NT) {
+    const int item = s_queue[i];
+    const int k = item >> 2, s = item & 3;
+    const int y = ty0 + k / CS_TW, x = tx0 + k % CS_TW;
+    const float* g = p.gxout + ((((long)s * p.B + b) * 2 + f) * 3) * plane + (long)y * W + x;
+    const float gv[3] = {g[0], g[plane], g[2 * plane]};
+    SampleAddr a;
+    sample_at(s, y, x, a);
+    const float ex = 1.0f - a.tx, ey = 1.0f - a.ty;
+    const float wt[4] = {ex * ey, a.tx * ey, ex * a.ty, a.tx * a.ty};
+    const int yy[4] = {a.y0, a.y0, a.y1, a.y1}, xx[4] = {a.x0, a.x1, a.x0, a.x1};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int py = yy[t] - oy, px = xx[t] - ox;
+      const bool in = (unsigned)py < (unsigned)CS_PH && (unsigned)px < (unsigned)CS_PW;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const unsigned long long q = to_fixed(gv[c] * wt[t]);
+        if (in) {
+          __hip_atomic_fetch_add(&s_patch[c][py * CS_PW + px], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          __hip_atomic_fetch_add(p.gcol + (((long)f * p.B + b) * 3 + c) * plane + (long)yy[t] * W + xx[t], q,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          spilled = true;
+        }
+      }
+    }
+  }
+  if (spilled) *p.spill_flag = 1u;  // every writer stores the same value
+  __syncthreads();
+  float* slot = p.slots + ((long)bt * 2 + f) * (3 * CS_PH * CS_PW);
+  for (int i = tid; i < 3 * CS_PH * CS_PW; i += CS_NT)
+    slot[i] = (float)((double)(long long)(&s_patch[0][0])[i] * (1.0 / 4294967296.0));
+  if (tid < 2) p.anchors[(long)bt * 4 + 2 * f + tid] = s_anchor[tid];
+}
+
+// Fixed-order sum of the slots that cover a source pixel (+ the rare-path image), scaled by the
+// upstream gradient and the 1 / (S * B * H * W) of the mean.  A block takes one CS_TH x CS_TW
+// region of one source image (two pixels per thread, three channels each) and walks over the
+// tiles whose patch can reach the region -- the same list for every thread, so the anchors are
+// scalar loads and the loop is uniform.
+__device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+__global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, const float* __restrict__ grad_loss,
+                                                           float inv_count, float* __restrict__ out0,
+                                                           float* __restrict__ out1) {
+  const int ntile = p.tilesX * p.tilesY;
+  const int f = blockIdx.x / (p.B * ntile);
+  const int r = blockIdx.x - f * p.B * ntile;
+  const int b = r / ntile, tile = r - b * ntile;
+  const int rY = tile / p.tilesX, rX = tile - rY * p.tilesX;
+  const int y_lo = rY * CS_TH, x_lo = rX * CS_TW;  // the region: rows y_lo .. y_lo + CS_TH - 1
+  const long plane = (long)p.H * p.W;
+  // a patch starts within CS_OFF_MAX of (its tile's origin - margin)
+  const int tY0 = max(0, floor_div(y_lo - CS_OFF_MAX + CS_MY - CS_PH + 1 + CS_TH - 1, CS_TH));
+  const int tY1 = min(p.tilesY - 1, floor_div(y_lo + CS_TH - 1 + CS_OFF_MAX + CS_MY, CS_TH));
+  const int tX0 = max(0, floor_div(x_lo - CS_OFF_MAX + CS_MX - CS_PW + 1 + CS_TW - 1, CS_TW));
+  const int tX1 = min(p.tilesX - 1, floor_div(x_lo + CS_TW - 1 + CS_OFF_MAX + CS_MX, CS_TW));
+  const int ky = threadIdx.x / (CS_TW / 2), kx = 2 * (threadIdx.x % (CS_TW / 2));
+  const int y = y_lo + ky, x = x_lo + kx;
+  float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  const long tbase = (long)b * ntile;
+  for (int tY = tY0; tY <= tY1; ++tY)
+    for (int tX = tX0; tX <= tX1; ++tX) {
+      const long t = tbase + (long)tY * p.tilesX + tX;
+      const int oy = p.anchors[t * 4 + 2 * f], ox = p.anchors[t * 4 + 2 * f + 1];
+      // does the patch meet the region at all (uniform)?
+      if (oy > y_lo + CS_TH - 1 || oy + CS_PH - 1 < y_lo || ox > x_lo + CS_TW - 1 || ox + CS_PW - 1 < x_lo) continue;
+      const int py = y - oy, px = x - ox;
+      const float* sl = p.slots + (t * 2 + f) * (3 * CS_PH * CS_PW) + py * CS_PW + px;
+      if ((unsigned)py < (unsigned)CS_PH) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if ((unsigned)(px + e) < (unsigned)CS_PW) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[e][c] += sl[c * CS_PH * CS_PW + e];
+          }
+      }
+    }
+  if (y >= p.H) return;
+  const bool spill = *p.spill_flag != 0u;
   const float g0 = grad_loss[0] * inv_count;
-  for (long i = (long)blockIdx.x * SM_NT + threadIdx.x; i < 2 * n_frame; i += (long)gridDim.x * SM_NT) {
-    const float v = (float)((double)gcol[i] * (1.0 / 4294967296.0));
-    if (i < n_frame)
-      out0[i] = g0 * v;
-    else
-      out1[i - n_frame] = g0 * v;
+  float* out = (f ? out1 : out0) + (long)b * 3 * plane + (long)y * p.W + x;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (x + e >= p.W) break;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = acc[e][c];
+      if (spill)
+        v += (float)((double)(long long)p.gcol[(((long)f * p.B + b) * 3 + c) * plane + (long)y * p.W + x + e] *
+                     (1.0 / 4294967296.0));
+      out[c * plane + e] = g0 * v;
+    }
   }
 }
 
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, gcol, total;
+  size_t tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, total;
+  // only with DW_FLAG_COLOR_GRAD: [color_zero_begin, color_zero_end) is cleared by every forward call
+  size_t gxout, slots, anchors, spill_flag, gcol, color_zero_begin, color_zero_end;
+  int cX, cY;  // tiles of the colour scatter
 };
 
 struct TileCounts {
@@ -1692,8 +1893,23 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   o = align_up(o + sizeof(float) * (size_t)DW_MAX_SCALES * d.B * 2, A);
   w.gdup = o;  // last section (the diagnostic stamps overwrite its start)
   o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
-  w.gcol = o;  // only with DW_FLAG_COLOR_GRAD
-  if (d.flags & DW_FLAG_COLOR_GRAD) o = align_up(o + sizeof(unsigned long long) * (size_t)2 * d.B * 3 * d.H * d.W, A);
+  w.cX = (d.W + CS_TW - 1) / CS_TW;
+  w.cY = (d.H + CS_TH - 1) / CS_TH;
+  w.gxout = w.slots = w.anchors = w.spill_flag = w.gcol = w.color_zero_begin = w.color_zero_end = o;
+  if (d.flags & DW_FLAG_COLOR_GRAD) {
+    const size_t ctiles = (size_t)d.B * w.cX * w.cY;
+    w.gxout = o;
+    o = align_up(o + sizeof(float) * (size_t)d.S * d.B * 6 * d.H * d.W, A);
+    w.slots = o;
+    o = align_up(o + sizeof(float) * ctiles * 2 * 3 * CS_PH * CS_PW, A);
+    w.anchors = o;
+    o = align_up(o + sizeof(int) * ctiles * 4, A);
+    w.color_zero_begin = w.spill_flag = o;
+    o = align_up(o + sizeof(unsigned), A);
+    w.gcol = o;
+    o = align_up(o + sizeof(unsigned long long) * (size_t)2 * d.B * 3 * d.H * d.W, A);
+    w.color_zero_end = o;
+  }
   w.total = o;
 }
 
@@ -1795,9 +2011,21 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
   const bool cgrad = with_grad && (desc->flags & DW_FLAG_COLOR_GRAD);
+  ColorParams cp{};
   if (cgrad) {
-    p.gcol = (unsigned long long*)(ws + w.gcol);
-    if (hipMemsetAsync(p.gcol, 0, w.total - w.gcol, st) != hipSuccess) return DW_ERR_LAUNCH;
+    p.gxout = (float*)(ws + w.gxout);
+    cp.B = p.B, cp.H = p.H, cp.W = p.W, cp.S = p.S;
+    cp.tilesX = w.cX, cp.tilesY = w.cY;
+    for (int s = 0; s < desc->S; ++s) cp.disp[s] = disp[s];
+    cp.K = K, cp.invK = inv_K, cp.T = T;
+    cp.gxout = p.gxout;
+    cp.gcol = (unsigned long long*)(ws + w.gcol);
+    cp.slots = (float*)(ws + w.slots);
+    cp.anchors = (int*)(ws + w.anchors);
+    cp.spill_flag = (unsigned*)(ws + w.spill_flag);
+    // the rare-path image and its flag start at zero
+    if (hipMemsetAsync(ws + w.color_zero_begin, 0, w.color_zero_end - w.color_zero_begin, st) != hipSuccess)
+      return DW_ERR_LAUNCH;
   }
 
   const int n_tiles = p.tilesX * p.tilesY * p.B;
@@ -1813,10 +2041,12 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
     return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
   }
   if (with_grad) {
-    if (cgrad)
+    if (cgrad) {
       photo_tile_color_kernel<<<tgrid, Geom<true>::NT, 0, st>>>(p);
-    else
+      color_scatter_kernel<<<2 * p.B * w.cX * w.cY, CS_NT, 0, st>>>(cp);
+    } else {
       photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
+    }
     smooth_kernel<true><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   } else {
     photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
@@ -1886,12 +2116,18 @@ extern "C" int dw_photometric_bwd_color(const dw_desc* desc, const float* grad_l
   TileCounts tc;
   make_layout(*desc, L, w, tc);
   if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return DW_ERR_WORKSPACE;
-  const long n_frame = (long)desc->B * 3 * desc->H * desc->W;
+  ColorParams cp{};
+  cp.B = desc->B, cp.H = desc->H, cp.W = desc->W, cp.S = desc->S;
+  cp.tilesX = w.cX, cp.tilesY = w.cY;
+  char* ws = (char*)workspace;  // read only
+  cp.gcol = (unsigned long long*)(ws + w.gcol);
+  cp.slots = (float*)(ws + w.slots);
+  cp.anchors = (int*)(ws + w.anchors);
+  cp.spill_flag = (unsigned*)(ws + w.spill_flag);
   const float inv_count = 1.0f / ((float)desc->S * (float)desc->B * (float)((long)desc->H * desc->W));
-  const long want = (2 * n_frame + SM_NT * 4 - 1) / (SM_NT * 4);
-  const int grid = (int)(want < 1 ? 1 : (want > 65536 ? 65536 : want));
-  grad_color_kernel<<<grid, SM_NT, 0, (hipStream_t)stream>>>(
-      (const long long*)((const char*)workspace + w.gcol), grad_loss, inv_count, grad_color[0], grad_color[1],
-      n_frame);
+  const long nblk = 2l * desc->B * w.cX * w.cY;
+  if (nblk > 0x7fffffffl) return DW_ERR_SHAPE;
+  grad_color_kernel<<<(unsigned)nblk, CS_NT, 0, (hipStream_t)stream>>>(cp, grad_loss, inv_count, grad_color[0],
+                                                                      grad_color[1]);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }

@@ -70,10 +70,12 @@ typedef struct dw_desc {
 /* Testing only: never split the last tiles of the launch into per-scale blocks
  * (the split is a scheduling choice; results are identical with and without). */
 #define DW_FLAG_NO_TAIL_SPLIT 2
-/* Also accumulate the gradient with respect to the two source images as the
+/* Also compute the gradient with respect to the two source images as the
  * warp samples them (the scatter adjoint of the bilinear warp; the identity
- * errors and the target image are not differentiated).  The workspace grows by
- * 48 * B * H * W bytes; read the result with dw_photometric_bwd_color.  Must be
+ * errors and the target image are not differentiated).  The workspace grows
+ * (about 190 * B * H * W bytes at four scales: per-pixel adjoints of the warped
+ * colours, per-tile patches, and a fixed-point image for the samples that leave
+ * their tile's patch); read the result with dw_photometric_bwd_color.  Must be
  * set identically for workspace_bytes, fwd (with_grad != 0) and the bwd calls. */
 #define DW_FLAG_COLOR_GRAD 4
 
@@ -141,8 +143,10 @@ DW_API int dw_photometric_bwd(const dw_desc* desc,
  * for the forward call that filled `workspace`.
  *   grad_loss     device scalar, upstream gradient of the loss
  *   grad_color    2 device pointers, (B,3,H,W) each, overwritten
- * The sums behind it are accumulated in 64-bit fixed point (2^-32 units), so
- * the result does not depend on the order of the additions. */
+ * The scatter is accumulated per tile in on-chip memory in 64-bit fixed point
+ * (2^-32 units) and the tiles' patches are summed per pixel in a fixed order, so
+ * the result does not depend on the order of execution; integer atomics in
+ * global memory are used only by samples that fall outside their tile's patch. */
 DW_API int dw_photometric_bwd_color(const dw_desc* desc,
                        const float* grad_loss,
                        const void* workspace, size_t workspace_bytes,

@@ -85,8 +85,9 @@ def test_flags_in_header_and_binding_agree_and_size_the_workspace():
     B, H, W = 3, 64, 96
     plain = lib.dw_photometric_workspace_bytes(_lib.DwDesc(B, H, W, 4, 2, 0))
     color = lib.dw_photometric_workspace_bytes(_lib.DwDesc(B, H, W, 4, 2, _lib.DW_FLAG_COLOR_GRAD))
-    # two source images, three channels, 64-bit fixed-point sums
-    assert color - plain == 2 * B * 3 * H * W * 8
+    # at least: the adjoints of the warped colours at every scale (2 frames x 3 channels, float32)
+    # and the fixed-point image of the rare path (2 source images, three channels, 64 bit)
+    assert color - plain >= 4 * B * 6 * H * W * 4 + 2 * B * 3 * H * W * 8
     assert lib.dw_photometric_workspace_bytes(_lib.DwDesc(B, H, W, 4, 2, 8)) == 0  # unknown flag
     # the colour-gradient read-out refuses a descriptor without its flag, before touching any pointer
     assert lib.dw_photometric_bwd_color(_lib.DwDesc(B, H, W, 4, 2, 0), None, None, 0, None, None) < 0

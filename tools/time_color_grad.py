@@ -1,6 +1,6 @@
 """Step time of the photometric stack with and without the source-image gradient (flag 4)."""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from depth_estimation_amd.ops import PhotometricPlan
 from depth_estimation_amd.synth import make_sequence
 
