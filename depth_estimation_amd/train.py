@@ -4,9 +4,10 @@ This is the build's counterpart of the reference's trainer step
 (/root/reference/train.py:96-153: forward, loss, zero_grad / backward / step),
 re-shaped for one process per GPU: every rank owns a shard of the batch, runs
 depth + pose networks (stock PyTorch convolutions -- out of the hot-path scope)
-and the HIP view-synthesis loss on it, and the only exchange is ONE all-reduce
-of a flat float32 gradient bucket plus the scalar loss (RCCL over xGMI on a
-GPU node; gloo on CPU for tests).  The reference itself is single-process
+and the HIP view-synthesis loss on it, and the only exchange is the all-reduce of a
+flat float32 gradient bucket plus the scalar loss (RCCL over xGMI on a GPU
+node; gloo on CPU for tests), issued in a few chunks from gradient hooks so
+that it overlaps the rest of backward.  The reference itself is single-process
 (train.py:348) and hard-wired to batch 1.
 
     python -m torch.distributed.run --nproc-per-node N -m depth_estimation_amd.train --steps 20
@@ -75,28 +76,84 @@ class PoseNet(nn.Module):
 
 
 class FlatGradBucket:
-    """All parameter gradients as views into one contiguous float32 buffer, so
-    the data-parallel exchange is a single all-reduce with no packing copies."""
+    """All parameter gradients as views into one contiguous float32 buffer (slot 0 holds the
+    scalar loss), so the data-parallel exchange needs no packing copies.  The buffer is cut into
+    `n_chunks` contiguous ranges in parameter order.  Backward fills them roughly last-to-first;
+    a hook on every parameter counts its chunk down and, when the chunk's last gradient has been
+    accumulated, starts that chunk's all-reduce at once (asynchronously, RCCL's own stream), so
+    the exchange of the late layers runs while backward is still working on the early ones.
+    `finish()` waits for the chunks and turns the sums into means."""
 
-    def __init__(self, params):
+    def __init__(self, params, n_chunks: int = 4):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)  # last slot: the loss
-        o = 0
+        self.flat = torch.zeros(1 + n, dtype=torch.float32, device=dev)  # slot 0: the loss
+        o = 1
+        bounds = []
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
+            bounds.append((o, o + p.numel()))
             o += p.numel()
+        # chunk c = parameters [first[c], first[c + 1]); chunk 0 also carries the loss slot
+        n_chunks = max(1, min(n_chunks, len(self.params)))
+        target, first, acc = n / n_chunks, [0], 0
+        for i, p in enumerate(self.params[:-1]):
+            acc += p.numel()
+            if acc >= target * len(first) and len(first) < n_chunks:
+                first.append(i + 1)
+        self._chunk_of = []
+        self._ranges = []
+        for c, lo in enumerate(first):
+            hi = first[c + 1] if c + 1 < len(first) else len(self.params)
+            self._chunk_of += [c] * (hi - lo)
+            self._ranges.append((0 if c == 0 else bounds[lo][0], bounds[hi - 1][1]))
+        self._size = [self._chunk_of.count(c) for c in range(len(first))]
+        self._left = list(self._size)
+        self._handles = []
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(lambda _p, c=self._chunk_of[i]: self._grad_ready(c))
+
+    @staticmethod
+    def _world() -> int:
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def begin(self, loss: torch.Tensor):
+        """Call before backward: clears the counters and stores the loss in its slot."""
+        self._left = list(self._size)
+        self._handles = []
+        self.flat[0] = loss.detach()
+
+    def _grad_ready(self, c: int):
+        self._left[c] -= 1
+        if self._left[c] == 0 and self._world() > 1:
+            lo, hi = self._ranges[c]
+            self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):
         self.flat.zero_()
 
+    def finish(self) -> torch.Tensor:
+        """Call after backward: waits for the chunk all-reduces, averages; returns the mean loss."""
+        world = self._world()
+        if world > 1:
+            if any(n != 0 for n in self._left):  # a parameter got no gradient this step: its chunk never fired
+                for h in self._handles:
+                    h.wait()
+                self._handles = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+                                 for c, (lo, hi) in enumerate(self._ranges) if self._left[c] != 0]
+            for h in self._handles:
+                h.wait()
+            self.flat.mul_(1.0 / world)
+        return self.flat[0]
+
     def all_reduce_mean(self, loss: torch.Tensor) -> torch.Tensor:
-        self.flat[-1] = loss.detach()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        """One blocking exchange of the whole buffer (no overlap with backward)."""
+        self.flat[0] = loss.detach()
+        if self._world() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / dist.get_world_size())
-        return self.flat[-1]
+            self.flat.mul_(1.0 / self._world())
+        return self.flat[0]
 
 
 class Trainer:
@@ -132,8 +189,9 @@ class Trainer:
     def step(self, seq: Sequence) -> float:
         self.bucket.zero()
         loss = self.forward_loss(seq)
-        loss.backward()
-        mean_loss = self.bucket.all_reduce_mean(loss)
+        self.bucket.begin(loss)
+        loss.backward()                    # chunk all-reduces start from the gradient hooks
+        mean_loss = self.bucket.finish()
         self.opt.step()
         return mean_loss
 

@@ -30,7 +30,7 @@ def _worker(rank, world, port, out):
         loss = tr.step(seq)
         w = torch.cat([p.detach().reshape(-1) for p in tr.bucket.params])
         # plain numpy payloads: torch tensors would travel as shared-memory handles that die with the worker
-        out.put((rank, float(loss), tr.bucket.flat[:-1].numpy().copy(), w.numpy().copy()))
+        out.put((rank, float(loss), tr.bucket.flat[1:].numpy().copy(), w.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -40,7 +40,7 @@ def test_two_rank_step_matches_full_batch():
     ref = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)
     full = make_sequence(B, H, W, seed=1)
     ref_loss = ref.step(full)
-    ref_grad = ref.bucket.flat[:-1].clone()
+    ref_grad = ref.bucket.flat[1:].clone()
     ref_w = torch.cat([p.detach().reshape(-1) for p in ref.bucket.params])
 
     ctx = mp.get_context("spawn")
@@ -62,6 +62,21 @@ def test_two_rank_step_matches_full_batch():
     assert rel <= 1e-3, rel
     assert float(ref_grad.abs().max()) > 0
     assert float((w0 - ref_w).abs().max()) <= 1e-4
+
+
+def test_bucket_chunks_cover_the_buffer_and_fire_once_per_step():
+    """The flat buffer is cut into contiguous chunks in parameter order; every chunk's counter
+    reaches zero exactly once per backward pass (that is when its all-reduce would start)."""
+    tr = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)
+    bk = tr.bucket
+    assert bk._ranges[0][0] == 0 and bk._ranges[-1][1] == bk.flat.numel()
+    for (lo, hi), (lo2, _) in zip(bk._ranges[:-1], bk._ranges[1:]):
+        assert hi == lo2 and hi > lo
+    assert sum(bk._size) == len(bk.params) and len(bk._ranges) == 4
+    tr.step(make_sequence(2, H, W, seed=3))
+    assert bk._left == [0] * len(bk._size)
+    tr.step(make_sequence(2, H, W, seed=3))
+    assert bk._left == [0] * len(bk._size)
 
 
 def test_trainer_without_gpu_needs_explicit_loss():
