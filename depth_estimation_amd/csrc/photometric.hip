@@ -972,6 +972,13 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         float gdepth[SW];
 #pragma unroll
         for (int q = 0; q < SW; ++q) gdepth[q] = 0.f;
+        // A wave none of whose pixels has a re-projection winner in its 3 x 3 neighbourhood (a region
+        // the auto-mask removed as a whole: static scene, texture-less sky) has no photometric
+        // gradient at all: the adjoint below would add exact zeros.  Uniform branch, no barrier inside.
+        bool wave_live = false;
+#pragma unroll
+        for (int q = 0; q < SW; ++q) wave_live = wave_live || live[q];
+        if (CGRAD || __builtin_amdgcn_ballot_w64(wave_live) != 0ull) {
         // Window-sum adjoint, one colour channel (three coefficient planes) at a
         // time and both frames in the same pass over LDS: `tot` is the sum over
         // all neighbours, `af0` over the neighbours where frame 0 won; frame 1's
@@ -1124,6 +1131,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
             gdepth[q] += gX * r0[q] + gY * r1[q] + gZ * r2[q];
           }
         }
+        }  // wave_live
 #pragma unroll
         for (int q = 0; q < SW; ++q) gd[q] = gdepth[q] * (-kDispRange * depth[q] * depth[q]);
       }
