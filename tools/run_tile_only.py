@@ -14,6 +14,7 @@ B, H, W = int(os.environ.get("DW_B", 12)), int(os.environ.get("DW_H", 192)), int
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 seq = make_sequence(B, H, W, seed=0).to("cuda")
 plan = PhotometricPlan(B, H, W, 4, "cuda", flags=1).bind(*seq.args())
+grad = os.environ.get("DW_GRAD", "1") != "0"   # DW_GRAD=0: the forward-only tile kernel
 for _ in range(n):
-    plan.forward(with_grad=True)
+    plan.forward(with_grad=grad)
 torch.cuda.synchronize()
