@@ -40,9 +40,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
-# vector-issue peak: 256 CUs x 4 SIMDs at 2.4 GHz, one plain float32 instruction of a 64-wide wave
-# every 2 cycles per SIMD (instructions counted as SQ_INSTS_VALU counts them, per wave)
-VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0
+# vector pipes: 256 CUs x 4 SIMDs at 2.4 GHz.  How long an instruction holds its SIMD's pipe depends
+# on the opcode and its operands (about 2.55 cycles for plain float32 arithmetic on vector registers,
+# about 4.5 for most other opcodes and for any opcode with a scalar-register operand, 8.3 for
+# transcendentals: tools/micro/valu_rates.hip); tools/valu_pipe_model.py turns the kernel's
+# instruction mix into an average number of pipe cycles per vector instruction.
+SIMD_CYCLES_PER_S = 1024 * 2.4e9
 DP_BUCKET_FLOATS = 3_200_000  # gradient bucket of the depth + pose networks (about 12.8 MB)
 
 
@@ -179,12 +182,14 @@ def roofline(args, seq, dev, alg_total):
         fresh = pmc.get("sources_sha") == kernel_sources_sha()
         if entry is not None and fresh:
             out["traffic"] = entry["bytes_corrected"]
-            insts = entry.get("SQ_INSTS_VALU")
-            if insts:
-                rate = insts / (k_ms * 1e-3)
-                limits.append({"bound": "valu_issue", "achieved": rate / 1e12, "peak": VALU_PEAK_WAVE_INSTS_PER_S / 1e12,
-                               "unit": "T wave-instructions/s", "frac": rate / VALU_PEAK_WAVE_INSTS_PER_S,
-                               "wave_instructions_per_launch": insts})
+            insts, per = entry.get("SQ_INSTS_VALU"), pmc.get("valu_pipe_cycles_per_inst")
+            if insts and per:
+                # time the vector pipes alone need for the instructions of one launch / measured time
+                pipe_ms = 1e3 * insts * per / SIMD_CYCLES_PER_S
+                limits.append({"bound": "valu_pipe", "achieved": pipe_ms, "peak": k_ms, "unit": "ms of vector-pipe "
+                               "time per launch (achieved) within the launch's duration (peak)",
+                               "frac": pipe_ms / k_ms, "wave_instructions_per_launch": insts,
+                               "pipe_cycles_per_instruction": per})
         elif entry is not None:
             out["traffic_stale"] = True  # counters of an older build: not reported
     out["limits"] = limits

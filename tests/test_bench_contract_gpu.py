@@ -27,7 +27,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["limits"][0]["bound"] == "hbm" and r["binding"] in ("hbm", "valu_issue")
+    assert r["limits"][0]["bound"] == "hbm" and r["binding"] in ("hbm", "valu_pipe")
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]

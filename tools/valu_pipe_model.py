@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """Vector-pipe cost model of the tile kernel.
 
-The vector pipe of a SIMD does not take the same time for every opcode: measured with
-tools/micro/valu_rates.hip (independent chains, four waves per SIMD, profiles/r02_valu_rates.txt),
-plain float32 arithmetic (fma, mul, add, sub, fmac, mov, 32-bit integer add) costs about 2.3
-cycles per wave-instruction, most other opcodes (compares, conversions, floor, integer min/max,
-shifts, selects, DPP, v_div_fixup, integer multiply) about 4.4, 64-bit adds about 4.8 and
-transcendentals (rcp, exp) about 8.4.  This script weights the opcode histogram of the kernel's
-segments (a -DDW_STAMPS assembly listing: the stamps split prologue, per-scale stages and
-epilogue) with those costs and with how often a segment runs per tile (the per-scale stages four
-times) and prints the average pipe cycles per vector instruction.  bench.py multiplies that
-figure with the SQ_INSTS_VALU counter to state the vector-pipe limit of a launch.
+The vector pipe of a SIMD does not take the same time for every instruction.  Measured with
+tools/micro/valu_rates.hip (independent chains, every CU busy; profiles/r02_valu_rates.txt), at
+two or four waves per SIMD:
+  * plain float32 / 32-bit add, sub, logic, mov opcodes in the 32-bit encoding with vector-register,
+    inline-constant operands: about 2.55 cycles per wave-instruction;
+  * the same in the 64-bit encoding (v_fma_f32, literal operands, neg / abs modifiers): about 3.0;
+  * every other opcode (compares, conversions, floor, min / max, shifts, selects, DPP, v_div_fixup,
+    integer multiply), AND any opcode of the first two groups with a scalar-register operand:
+    about 4.5;  64-bit adds about 4.8;  transcendentals (rcp, exp) about 8.3.
+This script weights the instructions of the kernel's segments (a -DDW_STAMPS assembly listing: the
+stamps split prologue, per-scale stages and epilogue) with those costs and with how often a
+segment runs per tile (the per-scale stages four times) and prints the average pipe cycles per
+vector instruction.  bench.py multiplies that figure with the SQ_INSTS_VALU counter to state the
+vector-pipe limit of a launch.
 
 usage: valu_pipe_model.py LISTING.s [--write]   (--write: store the figure in profiles/traffic_latest.json)
 """
@@ -21,18 +25,22 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FULL = 2.3
-HALF = 4.4
+FULL32 = 2.55   # 32-bit encoding, vector-register / inline-constant operands
+FULL64 = 3.0    # 64-bit encoding of the same opcodes
+HALF = 4.5
 WIDE = 4.8
-TRANS = 8.4
+TRANS = 8.3
 FULL_RATE = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_fmac_f32", "v_fmaak_f32",
-             "v_fmamk_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32"}
+             "v_fmamk_f32", "v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32",
+             "v_xor_b32", "v_ashrrev_i32"}
+ALWAYS64 = {"v_fma_f32", "v_fmaak_f32", "v_fmamk_f32"}
 TRANSCENDENTAL = {"v_rcp_f32", "v_rcp_iflag_f32", "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_rsq_f32"}
 WIDE_OPS = {"v_lshl_add_u64", "v_mad_u64_u32", "v_lshlrev_b64", "v_mov_b64"}
 PER_TILE = {6: 4, 8: 4, 9: 4, 10: 4, 11: 4}   # segments inside the scale loop (see tools/kseg.py)
 
 
-def cost(op: str) -> float:
+def cost(line: str) -> float:
+    op = line.split()[0]
     base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
     if op.endswith("_dpp"):
         return HALF
@@ -41,28 +49,33 @@ def cost(op: str) -> float:
     if base in WIDE_OPS:
         return WIDE
     if base in FULL_RATE:
-        return FULL
+        srcs = line.split(None, 1)[1].split(",")[1:]
+        if any(re.match(r"\s*-?\|?(s\d+|s\[|vcc|exec)", x) for x in srcs):
+            return HALF     # a scalar-register operand
+        if base in ALWAYS64 or op.endswith("_e64") or any(re.search(r"0x[0-9a-f]+|\|| -v", x) for x in srcs):
+            return FULL64
+        return FULL32
     return HALF
 
 
 def main():
     text = open(sys.argv[1]).read()
     m = re.search(r"^_ZN2dw17photo_tile_kernelILb1EEEvNS_11PhotoParamsE:(.*?)\.Lfunc_end", text, re.S | re.M)
-    segs = [collections.Counter()]
+    segs = [[]]
     for ln in m.group(1).split("\n"):
         t = ln.strip()
         if not t or t.startswith((".", ";", "//")) or t.endswith(":"):
             continue
         op = t.split()[0]
         if op == "s_memtime":
-            segs.append(collections.Counter())
+            segs.append([])
         elif op.startswith("v_"):
-            segs[-1][op] += 1
+            segs[-1].append(t)
     insts = cycles = 0.0
     for i, seg in enumerate(segs):
         w = PER_TILE.get(i, 1)
-        n = sum(seg.values())
-        c = sum(k * cost(op) for op, k in seg.items())
+        n = len(seg)
+        c = sum(cost(t) for t in seg)
         insts += w * n
         cycles += w * c
         if n > 20:
