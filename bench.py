@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--net-width", type=int, default=64,
                     help="base channel count of the depth / pose networks in train mode (64: about 4 M parameters)")
+    ap.add_argument("--amp", action="store_true",
+                    help="train mode: run the networks under bfloat16 autocast (the loss op stays float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="sequences in the CPU baseline sample")
     args = ap.parse_args(argv)
@@ -310,7 +312,7 @@ def run_train(args, ctx):
     dev, rank, world = ctx["dev"], ctx["rank"], ctx["world"]
     B, H, W, S = args.batch, args.height, args.width, 4
     seq = make_sequence(B, H, W, S=S, seed=rank).to(dev)
-    trainer = Trainer(dev, width=args.net_width)
+    trainer = Trainer(dev, width=args.net_width, amp=args.amp)
     for _ in range(3):
         trainer.step(seq)
     torch.cuda.synchronize()
@@ -342,7 +344,8 @@ def run_train(args, ctx):
     return {
         "metric": "full training step throughput", "value": 3 * B * world / per_step, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (networks under bf16 autocast)" if args.amp else "f32", "data": "synthetic",
         "config": {"workload": f"full training step (depth + pose networks on PyTorch-ROCm, HIP warp/loss op, "
                                f"gradient all-reduce, Adam), {H}x{W}, batch={B}/GPU, 2 source frames, 4 scales",
                    "mode": "train", "global_batch": B * world, "network_parameters": n_params},

@@ -698,7 +698,11 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
     };
     // issue: geometry, projection into both frames and all 24 taps of region pixel i
     auto setup = [&](int i, Px& q, SampleAddr* qa, SampleTaps* qt) __attribute__((always_inline)) {
-      asm volatile("" : "+v"(i));  // keep per-pixel geometry from being hoisted out of the scale loop
+      // The region coordinates of the two full passes do not depend on the scale.  The gradient
+      // kernel lets the compiler keep them in registers across the scale loop (saves their
+      // half-rate integer arithmetic: 1 % of the kernel); the forward-only kernel, compiled for
+      // 168 registers, recomputes them per scale instead of spilling.
+      if (!GRAD) asm volatile("" : "+v"(i));
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
       q.li = ry * RP + rx;
@@ -752,7 +756,7 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       const int pi = wid * LEFT_PER_WAVE + h;
       q.act = h < LEFT_PER_WAVE && pi < LEFT;
       int i = NFULL * NT + (q.act ? pi : 0);
-      asm volatile("" : "+v"(i));
+      asm volatile("" : "+v"(i));  // recomputed per scale: keeping these as well costs scalar-register spills
       const int ry = i / RW, rx = i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
       q.li = ry * RP + rx;

@@ -158,8 +158,11 @@ class FlatGradBucket:
 
 class Trainer:
     def __init__(self, device, loss_fn: Optional[LossFn] = None, lr: float = 1e-4, width: int = 16,
-                 seed: int = 0):
+                 seed: int = 0, amp: bool = False):
         self.device = torch.device(device)
+        # amp: the networks run under bfloat16 autocast (their convolutions are stock PyTorch and out of
+        # this build's scope); the view-synthesis loss always gets and returns float32
+        self.amp = amp
         if loss_fn is None:
             if self.device.type != "cuda":
                 from ._lib import DepthwarpError
@@ -177,12 +180,14 @@ class Trainer:
 
     def forward_loss(self, seq: Sequence) -> torch.Tensor:
         tgt, prev, nxt = seq.color
-        disp = [d.contiguous() for d in self.depth_net(tgt)]
+        with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.amp):
+            disp = self.depth_net(tgt)
+            poses = [self.pose_net(prev, tgt), self.pose_net(tgt, nxt)]
+        disp = [d.float().contiguous() for d in disp]
         Ts = []
-        for f, src in enumerate((prev, nxt)):
+        for f, (aa, tr) in enumerate(poses):
             # frame -1 is predicted in temporal order and inverted, as is customary
-            aa, tr = self.pose_net(src, tgt) if f == 0 else self.pose_net(tgt, src)
-            Ts.append(pose_to_matrix(aa, tr, invert=(f == 0)))
+            Ts.append(pose_to_matrix(aa.float(), tr.float(), invert=(f == 0)))
         T = torch.stack(Ts, 1).contiguous()
         return self.loss_fn(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T, None)
 
