@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """HIP path against the CPU oracle over many seeds and a few shapes, with poses from mild to
-extreme: masks must be equal bit for bit, loss within 1e-5, gradients within 1e-4 (max-norm;
-disparity gradients outside the smoothness ties, see tests/test_photometric_gpu.py).
+extreme (translations grow with the seed: tens of metres beyond seed 100): masks must be equal bit
+for bit, loss within 1e-5, gradients within 1e-4 (max-norm; disparity gradients outside the
+smoothness ties, see tests/test_photometric_gpu.py).  A gradient outside the bar is re-examined
+against the oracle evaluated in float64: it counts as explained if the float32 oracle itself is
+that far from the float64 one (an ill-conditioned pose), as unexplained otherwise.
 usage: parity_sweep.py [seeds] [summary.json]"""
 import json
 import os
@@ -16,12 +19,13 @@ from oracle import photometric as ph  # noqa: E402
 from tests.test_photometric_gpu import smoothness_ties, sweep_case  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+SHAPES = ((2, 32, 96), (1, 48, 160), (1, 40, 104), (1, 192, 640))
 bad = 0
 failures = []
 n_ties = 0
 worst = [0.0, 0.0, 0.0]
 for seed in range(n):
-    for B, H, W in ((2, 32, 96), (1, 48, 160), (1, 40, 104)):
+    for B, H, W in SHAPES:
         seq = sweep_case(seed, B, H, W)
         disp = [d.clone().requires_grad_(True) for d in seq.disp]
         T = seq.T.clone().requires_grad_(True)
@@ -29,6 +33,7 @@ for seed in range(n):
                                          return_aux=True)
         loss.backward()
         masks = torch.stack([ph.pack_mask(aux["idx"][s], aux["valid"][s]) for s in range(4)])
+        n_masks = n_masks + 4 if "n_masks" in dir() else 4
         gq = seq.to("cuda")
         hd = [d.clone().requires_grad_(True) for d in gq.disp]
         hT = gq.T.clone().requires_grad_(True)
@@ -44,14 +49,35 @@ for seed in range(n):
         nm = int((mask.cpu() != masks).sum())
         worst = [max(worst[0], e_loss), max(worst[1], e_gd), max(worst[2], e_gT)]
         if nm or e_loss > 1e-5 or e_gd > 1e-4 or e_gT > 1e-4:
-            bad += 1
+            # A gradient outside the bar: is the case ill-conditioned in float32?  Yardstick: the same
+            # oracle evaluated in float64.  The kernel passes if it is no further from that than twice
+            # the float32 oracle is (plus the bar), as in test_parity_sweep_outlier_ill_conditioned_pose.
+            s64 = seq.to("cpu", torch.float64)
+            d64 = [d.clone().requires_grad_(True) for d in s64.disp]
+            T64 = s64.T.clone().requires_grad_(True)
+            ph.photometric_stack(d64, s64.color, s64.color_pyr, s64.K, s64.inv_K, T64, s64.tie_noise).backward()
+            ok = nm == 0 and e_loss <= 1e-5
+            yard = {"grad_disp_f32_vs_f64": 0.0, "grad_disp_hip_vs_f64": 0.0}
+            for h, d, d6, t in zip(hd, disp, d64, ties):
+                keep = (~t).double()
+                sc = d6.grad.abs().max()
+                e_h = float(((h.grad.cpu().double() - d6.grad).abs() * keep).max() / sc)
+                e_o = float(((d.grad.double() - d6.grad).abs() * keep).max() / sc)
+                yard["grad_disp_f32_vs_f64"] = max(yard["grad_disp_f32_vs_f64"], e_o)
+                yard["grad_disp_hip_vs_f64"] = max(yard["grad_disp_hip_vs_f64"], e_h)
+                ok = ok and e_h <= 2 * e_o + 1e-4
+            scT = T64.grad[:, :, :3].abs().max().clamp_min(1e-300)
+            yard["grad_T_hip_vs_f64"] = float((hT.grad.cpu().double()[:, :, :3] - T64.grad[:, :, :3]).abs().max() / scT)
+            yard["grad_T_f32_vs_f64"] = float((T.grad.double()[:, :, :3] - T64.grad[:, :, :3]).abs().max() / scT)
+            ok = ok and yard["grad_T_hip_vs_f64"] <= 2 * yard["grad_T_f32_vs_f64"] + 1e-4
+            bad += 0 if ok else 1
             failures.append({"seed": seed, "shape": [B, H, W], "mask_mismatches": nm, "loss": e_loss, "grad_disp": e_gd,
-                             "grad_T": e_gT})
+                             "grad_T": e_gT, "ill_conditioned_in_float32": ok, **yard})
             print(f"seed {seed} {B}x{H}x{W}: mask mismatches {nm}, loss {e_loss:.2e}, gd {e_gd:.2e}, gT {e_gT:.2e}",
                   flush=True)
     if seed % 5 == 4:
         print(f"seed {seed}: failures so far {bad}, worst loss/gd/gT {worst}", flush=True)
-summary = {"seeds": n, "cases": 3 * n, "failures": failures, "smoothness_tie_pixels_excluded": n_ties,
+summary = {"unexplained_failures": bad, "seeds": n, "shapes": [list(t) for t in SHAPES], "cases": len(SHAPES) * n, "outside_the_bar": failures, "smoothness_tie_pixels_excluded": n_ties,
            "worst_rel_err": {"loss": worst[0], "grad_disp": worst[1], "grad_T": worst[2]},
            "bars": {"masks": "bit-exact", "loss": 1e-5, "grad": 1e-4}}
 print(json.dumps(summary), flush=True)
