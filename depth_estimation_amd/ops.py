@@ -208,6 +208,7 @@ class PhotometricPlan:
         self.one = torch.ones(1, dtype=torch.float32, device=dev)
         self._mask_ptrs = _lib.ptr_array([self.mask[s] for s in range(S)])
         self._gd_ptrs = _lib.ptr_array(self.grad_disp)
+        self.generation = 0  # forward passes so far (lets an autograd node notice a later forward)
         self.grad_color = None
         if flags & DW_FLAG_COLOR_GRAD:
             self.grad_color = [torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
@@ -302,7 +303,6 @@ class PlanLoss:
         plan = self._plans.get(key)
         if plan is None:
             plan = self._plans[key] = PhotometricPlan(B, H, W, len(disp), color[0].device)
-            plan.generation = 0
         plan.bind([d.detach() for d in disp], color, color_pyr, K, inv_K, T.detach(), tie_noise)
         need = torch.is_grad_enabled() and (any(d.requires_grad for d in disp) or T.requires_grad)
         terms, mask = _PlanFunction.apply(plan, need, T, *disp)

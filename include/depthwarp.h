@@ -73,7 +73,7 @@ typedef struct dw_desc {
 /* Also compute the gradient with respect to the two source images as the
  * warp samples them (the scatter adjoint of the bilinear warp; the identity
  * errors and the target image are not differentiated).  The workspace grows
- * (about 190 * B * H * W bytes at four scales: per-pixel adjoints of the warped
+ * (about 220 * B * H * W bytes at four scales: per-pixel adjoints of the warped
  * colours, per-tile patches, and a fixed-point image for the samples that leave
  * their tile's patch); read the result with dw_photometric_bwd_color.  Must be
  * set identically for workspace_bytes, fwd (with_grad != 0) and the bwd calls. */

@@ -27,7 +27,10 @@ from oracle import compute_loss as cl  # noqa: E402
 PHOTO_CASES = [dict(B=2, H=24, W=80, seed=0, tie=False), dict(B=2, H=48, W=160, seed=0, tie=False),
                dict(B=1, H=32, W=96, seed=5, tie=True)]
 CL_CASES = [dict(B=1, Ht=375, Wt=1242, H=64, W=128, seed=0), dict(B=1, Ht=375, Wt=1242, H=256, W=512, seed=1),
-            dict(B=2, Ht=64, Wt=128, H=64, W=128, seed=2), dict(B=1, Ht=100, Wt=300, H=48, W=160, seed=3)]
+            dict(B=2, Ht=64, Wt=128, H=64, W=128, seed=2), dict(B=1, Ht=100, Wt=300, H=48, W=160, seed=3),
+            # the anti-aliased resize of the ground truth (the other torchvision default)
+            dict(B=1, Ht=375, Wt=1242, H=256, W=512, seed=1, aa=True),
+            dict(B=2, Ht=100, Wt=300, H=48, W=160, seed=4, aa=True)]
 
 
 def photo_case(c):
@@ -69,6 +72,16 @@ def cl_inputs(c):
     return target, pred
 
 
+def write_compute_loss():
+    rows = {}
+    for i, c in enumerate(CL_CASES):
+        t, p = cl_inputs(c)
+        terms = cl.compute_loss_terms(t, p, antialias=c.get("aa", False))
+        rows[f"case{i}"] = np.stack([terms[k].numpy() for k in ("loss", "ssim_term", "l1", "smooth")], 1)
+    np.savez_compressed(os.path.join(HERE, "compute_loss.npz"), **rows)
+    print("wrote compute_loss.npz")
+
+
 def main():
     for c in PHOTO_CASES:
         name = f"photo_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}{'_tie' if c['tie'] else ''}.npz"
@@ -78,13 +91,7 @@ def main():
         name = f"colorgrad_B{c['B']}_{c['H']}x{c['W']}_s{c['seed']}.npz"
         np.savez_compressed(os.path.join(HERE, name), **color_case(c))
         print("wrote", name)
-    rows = {}
-    for i, c in enumerate(CL_CASES):
-        t, p = cl_inputs(c)
-        terms = cl.compute_loss_terms(t, p)
-        rows[f"case{i}"] = np.stack([terms[k].numpy() for k in ("loss", "ssim_term", "l1", "smooth")], 1)
-    np.savez_compressed(os.path.join(HERE, "compute_loss.npz"), **rows)
-    print("wrote compute_loss.npz")
+    write_compute_loss()
 
 
 if __name__ == "__main__":

@@ -80,6 +80,6 @@ def test_hip_matches_committed_golden_vectors():
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "compute_loss.npz"))
     for i, c in enumerate(CL_CASES):
         t, p = cl_inputs(c)
-        terms = compute_loss_terms(t.cuda(), p.cuda())
+        terms = compute_loss_terms(t.cuda(), p.cuda(), antialias=c.get("aa", False))
         got = np.stack([terms[k].cpu().numpy() for k in ("loss", "ssim_term", "l1", "smooth")], 1)
         assert np.allclose(got, gold[f"case{i}"], rtol=RTOL, atol=0), (i, got, gold[f"case{i}"])

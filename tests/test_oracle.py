@@ -177,7 +177,7 @@ def test_compute_loss_oracle_closed_forms_and_golden():
     gold = np.load(os.path.join(GOLDEN, "compute_loss.npz"))
     for i, c in enumerate(CL_CASES):
         tgt, pred = cl_inputs(c)
-        terms = cl.compute_loss_terms(tgt, pred)
+        terms = cl.compute_loss_terms(tgt, pred, antialias=c.get("aa", False))
         got = np.stack([terms[k].numpy() for k in ("loss", "ssim_term", "l1", "smooth")], 1)
         assert np.allclose(got, gold[f"case{i}"], rtol=1e-6, atol=0)
     # the reference call shape: (1,Ht,Wt) float64 target, (1,H,W) float32 prediction -> 0-dim
