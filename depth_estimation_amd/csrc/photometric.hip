@@ -691,6 +691,11 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
     constexpr int NFULL = (RH * RW) / NT, LEFT = RH * RW - NFULL * NT;
     constexpr int LEFT_PER_WAVE = (LEFT + NT / kWave - 1) / (NT / kWave);
     constexpr bool SPLIT_LEFT = LEFT > 0 && LEFT_PER_WAVE <= 32;
+    // With two-pixel strips the full passes are exactly the error-map region Q (2 * NT pixels) and
+    // the rest is exactly the one-pixel ring of R around it.  Ring pixels are needed for the
+    // windows only: they are never stashed and need no derivatives, and no pixel of a full pass
+    // has to ask whether it is stashed.
+    constexpr bool QMAP = GRAD && SPLIT_LEFT && NFULL * NT == QH * QW && LEFT == 2 * RW + 2 * QH;
     struct Px {
       int li, sti;
       bool stash, act;
@@ -703,10 +708,10 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       // half-rate integer arithmetic: 1 % of the kernel); the forward-only kernel, compiled for
       // 168 registers, recomputes them per scale instead of spilling.
       if (!GRAD) asm volatile("" : "+v"(i));
-      const int ry = i / RW, rx = i - ry * RW;
+      const int ry = QMAP ? i / QW + 1 : i / RW, rx = QMAP ? i % QW + 1 : i - ry * RW;
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
       q.li = ry * RP + rx;
-      q.stash = (unsigned)(ry - 1) < (unsigned)QH && (unsigned)(rx - 1) < (unsigned)QW;
+      q.stash = QMAP || ((unsigned)(ry - 1) < (unsigned)QH && (unsigned)(rx - 1) < (unsigned)QW);
       q.sti = (ry - 1) * QW + (rx - 1);
       const float depth = s_depth[s * RN + q.li];
       const float fx = (float)x, fy = (float)y;
@@ -757,10 +762,17 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
       q.act = h < LEFT_PER_WAVE && pi < LEFT;
       int i = NFULL * NT + (q.act ? pi : 0);
       asm volatile("" : "+v"(i));  // recomputed per scale: keeping these as well costs scalar-register spills
-      const int ry = i / RW, rx = i - ry * RW;
+      int ry = i / RW, rx = i - ry * RW;
+      if (QMAP) {
+        // ring pixel k: top row, bottom row, then the left / right column pixel of rows 1 .. QH
+        const int k = i - NFULL * NT;
+        const int ks = k - 2 * RW;
+        ry = k < RW ? 0 : (k < 2 * RW ? RH - 1 : 1 + (ks >> 1));
+        rx = k < RW ? k : (k < 2 * RW ? k - RW : ((ks & 1) ? RW - 1 : 0));
+      }
       const int y = reflect_index(ry0 + ry, H), x = reflect_index(rx0 + rx, W);
       q.li = ry * RP + rx;
-      q.stash = (unsigned)(ry - 1) < (unsigned)QH && (unsigned)(rx - 1) < (unsigned)QW;
+      q.stash = !QMAP && (unsigned)(ry - 1) < (unsigned)QH && (unsigned)(rx - 1) < (unsigned)QW;
       q.sti = (ry - 1) * QW + (rx - 1);
       const float depth = s_depth[s * RN + q.li];
       const float fx = (float)x, fy = (float)y;
@@ -784,14 +796,14 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
     auto finish_left = [&](const Px& q, const SampleAddr& qa, const SampleTaps& qt) __attribute__((always_inline)) {
       const int f = q.f;
       Sample sm;
-      sample_blend<GRAD>(qa, qt, sm);
+      sample_blend<GRAD && !QMAP>(qa, qt, sm);
       const unsigned vb = qa.vb;
       const unsigned other = (unsigned)__shfl_xor((int)vb, 32, kWave);  // the other frame's bits of this pixel
       if (q.act) {
         s_un[(f * 3 + 0) * RN + q.li] = sm.val[0];
         s_un[(f * 3 + 1) * RN + q.li] = sm.val[1];
         s_un[(f * 3 + 2) * RN + q.li] = sm.val[2];
-        if (GRAD && q.stash) {
+        if (GRAD && !QMAP && q.stash) {
           float* st = &s_st[f * 9 * QH * QW + q.sti];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
