@@ -103,6 +103,9 @@ struct PhotoParams {
   int tilesX, tilesY;  // of the kernel being launched
   int n_full;          // blocks [0, n_full) run every scale of one tile; the rest one scale each
   int vec4;            // every scale's width is a multiple of 4 and every map pointer 16-byte aligned
+  // (H >> s) / H and (W >> s) / W as the float32 quotients the up-sampling formula uses: the same
+  // for every thread, so the host divides once instead of every lane of every block
+  float rsy[DW_MAX_SCALES], rsx[DW_MAX_SCALES];
   const float* disp[DW_MAX_SCALES];
   const float* color[3];
   const float* pyr[DW_MAX_SCALES];
@@ -160,12 +163,14 @@ __device__ __forceinline__ float tap(GlobalFloats base, unsigned byte_off) {
 #ifndef DW_UNIFORM_PTR
 #define DW_UNIFORM_PTR 0
 #endif
-__device__ __forceinline__ GlobalFloats uniform_ptr(const float* ptr) {
-  if (!DW_UNIFORM_PTR) return (GlobalFloats)ptr;
+__device__ __forceinline__ GlobalFloats scalar_ptr(GlobalFloats ptr) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
   const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (GlobalFloats)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ GlobalFloats uniform_ptr(const float* ptr) {
+  return DW_UNIFORM_PTR ? scalar_ptr((GlobalFloats)ptr) : (GlobalFloats)ptr;
 }
 
 // IEEE division in fewer instructions.  hipcc expands n / d into: scale both
@@ -482,8 +487,8 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
 #pragma unroll
     for (int s = 0; s < DW_MAX_SCALES; ++s) {
       const int sc = (s >= s_lo && s < s_hi) ? s : s_lo;
-      rsy[s] = uniform((float)(H >> sc) / (float)H);
-      rsx[s] = uniform((float)(W >> sc) / (float)W);
+      rsy[s] = p.rsy[sc];
+      rsx[s] = p.rsx[sc];
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -679,8 +684,6 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
   const long tslot = tslot_i;
 
   for (int s = s_lo; s < s_hi; ++s) {
-    const int hs = H >> s, ws = W >> s;
-    const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
     float loss_acc = 0.f;
 
     DW_STAMP(0)
@@ -2011,6 +2014,10 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.tilesX = with_grad ? tc.gX : tc.fX;
   p.tilesY = with_grad ? tc.gY : tc.fY;
   p.vec4 = 1;
+  for (int s = 0; s < DW_MAX_SCALES; ++s) {
+    p.rsy[s] = (float)(desc->H >> s) / (float)desc->H;
+    p.rsx[s] = (float)(desc->W >> s) / (float)desc->W;
+  }
   for (int s = 0; s < desc->S; ++s) {
     if (!disp[s] || !color_pyr[s]) return DW_ERR_NULL;
     p.disp[s] = disp[s];
