@@ -287,7 +287,7 @@ def run_op(args, ctx):
         "hbm_gbps_algorithmic": world * alg["total"] / per_step / 1e9,
         "loss": float(plan.loss[0].item()),
     }
-    if dp and world > 1 and not ctx["rehearsal"]:
+    if dp and dist is not None and not ctx["rehearsal"]:
         # the collective alone, same payload, for the record
         for _ in range(5):
             dist.all_reduce(bucket)
@@ -392,7 +392,9 @@ def main(argv=None):
     # device 0 and uses gloo for the collectives (RCCL refuses two ranks per device).
     rehearsal = os.environ.get("DW_BENCH_REHEARSAL") == "1"
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:
+        # under a launcher the collectives run even at world size 1 (one-rank RCCL communicator),
+        # so that a one-GPU box exercises the same calls as a node does
         import torch.distributed as dist
         if rehearsal:
             local = 0

@@ -63,3 +63,29 @@ def test_train_mode_reports_the_share_of_the_loss_op():
     d = _run(["--mode", "train", "--steps", "5", "--warmup", "2", "--net-width", "16"])
     assert d["config"]["mode"] == "train" and d["n_gpus"] == 1 and d["config"]["global_batch"] == 12
     assert 0 < d["loss_op_share"] < 1 and d["loss_op_ms"] > 0
+
+
+def _run_launched(args):
+    """The multi-GPU command form of the benchmark contract, with one rank: RCCL initialisation,
+    barrier, all-reduce and teardown run as they do on a node."""
+    sys.path.insert(0, ROOT)
+    from bench import free_port
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DW_BENCH_REHEARSAL"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", *args]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_one_rank_under_the_launcher_runs_the_collectives_over_rccl():
+    d = _run_launched(["--mode", "dp", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 16 and d["allreduce_ms"] > 0
+    d = _run_launched(["--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 12
+    d = _run_launched(["--mode", "train", "--steps", "3", "--warmup", "1", "--net-width", "16"])
+    assert d["n_gpus"] == 1 and d["config"]["mode"] == "train"
