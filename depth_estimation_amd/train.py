@@ -124,9 +124,15 @@ class FlatGradBucket:
         self._handles = []
         self.flat[0] = loss.detach()
 
+    @staticmethod
+    def _exchanging() -> bool:
+        """True inside a process group, also one of a single rank: the collectives then run as they
+        do on a node (a one-rank all-reduce leaves the data as it is)."""
+        return dist.is_available() and dist.is_initialized()
+
     def _grad_ready(self, c: int):
         self._left[c] -= 1
-        if self._left[c] == 0 and self._world() > 1:
+        if self._left[c] == 0 and self._exchanging():
             lo, hi = self._ranges[c]
             self._handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -136,7 +142,7 @@ class FlatGradBucket:
     def finish(self) -> torch.Tensor:
         """Call after backward: waits for the chunk all-reduces, averages; returns the mean loss."""
         world = self._world()
-        if world > 1:
+        if self._exchanging():
             if any(n != 0 for n in self._left):  # a parameter got no gradient this step: its chunk never fired
                 for h in self._handles:
                     h.wait()
@@ -150,7 +156,7 @@ class FlatGradBucket:
     def all_reduce_mean(self, loss: torch.Tensor) -> torch.Tensor:
         """One blocking exchange of the whole buffer (no overlap with backward)."""
         self.flat[0] = loss.detach()
-        if self._world() > 1:
+        if self._exchanging():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self._world())
         return self.flat[0]
@@ -191,7 +197,9 @@ class Trainer:
         T = torch.stack(Ts, 1).contiguous()
         return self.loss_fn(disp, seq.color, seq.color_pyr, seq.K, seq.inv_K, T, None)
 
-    def step(self, seq: Sequence) -> float:
+    def step(self, seq: Sequence) -> torch.Tensor:
+        """One optimisation step on this rank's shard; returns the loss averaged over the ranks
+        (a 0-dim device tensor: reading it is the caller's synchronisation, not the step's)."""
         self.bucket.zero()
         loss = self.forward_loss(seq)
         self.bucket.begin(loss)
@@ -223,7 +231,7 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:
         dist.init_process_group("nccl", device_id=dev)
     trainer = Trainer(dev)
     seq = make_sequence(args.batch, args.height, args.width, seed=rank).to(dev)
@@ -237,7 +245,7 @@ def main(argv=None):
     if rank == 0:
         print(f"loss {float(loss):.5f}  {1e3 * dt:.2f} ms/step  "
               f"{3 * args.batch * world / dt:.0f} frames/s on {world} GPU(s)")
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -26,3 +26,35 @@ def test_step_gradients_match_oracle_driven_step():
     assert rel <= 2e-3, rel
     w_after = torch.cat([p.detach().reshape(-1) for p in gpu.bucket.params])
     assert not torch.equal(w_before, w_after)
+
+
+def test_plan_loss_matches_the_allocating_op_and_accumulates_on_leaves():
+    """PlanLoss hands autograd gradients that alias the plan's buffers: leaf tensors must still
+    receive copies (two steps without clearing accumulate to exactly twice one step's gradient),
+    and values equal those of the per-call-allocating custom op bit for bit."""
+    from depth_estimation_amd.ops import PlanLoss, photometric_stack
+    from depth_estimation_amd.synth import make_sequence
+
+    seq = make_sequence(2, 48, 96, seed=11).to("cuda")
+
+    def leaves():
+        return [d.clone().requires_grad_(True) for d in seq.disp], seq.T.clone().requires_grad_(True)
+
+    disp_a, T_a = leaves()
+    photometric_stack(disp_a, seq.color, seq.color_pyr, seq.K, seq.inv_K, T_a).backward()
+    loss_fn = PlanLoss()
+    disp_b, T_b = leaves()
+    for _ in range(2):
+        loss_fn(disp_b, seq.color, seq.color_pyr, seq.K, seq.inv_K, T_b).backward()
+    for a, b in zip(disp_a + [T_a], disp_b + [T_b]):
+        assert torch.equal(2 * a.grad, b.grad)
+    # a second shape gets a plan of its own; the first shape's pending loss is refused once its
+    # plan has run again
+    first = loss_fn(disp_b, seq.color, seq.color_pyr, seq.K, seq.inv_K, T_b)
+    loss_fn(disp_b, seq.color, seq.color_pyr, seq.K, seq.inv_K, T_b)
+    with pytest.raises(RuntimeError):
+        first.backward()
+    # per-scale terms are differentiable through the plan as through the op
+    disp_c, T_c = leaves()
+    loss_fn.terms(disp_c, seq.color, seq.color_pyr, seq.K, seq.inv_K, T_c)[2].backward()
+    assert float(disp_c[1].grad.abs().max()) > 0 and float(disp_c[0].grad.abs().max()) == 0
