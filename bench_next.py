@@ -50,9 +50,11 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--only", choices=["soft_argmin", "cost_volume", "metrics", "lidar"], default=None)
+    ap.add_argument("--only", choices=["compute_loss", "soft_argmin", "cost_volume", "metrics", "lidar"], default=None)
     args = ap.parse_args()
     torch.cuda.set_device(0)
+    if args.only in (None, "compute_loss"):
+        bench_compute_loss(args)
     if args.only in (None, "soft_argmin"):
         bench_soft_argmin(args)
     if args.only in (None, "cost_volume"):
@@ -82,6 +84,43 @@ def cpu_time(fn, budget_s=10.0, max_n=10):
         fn()
         n += 1
     return (time.perf_counter() - t0) / n, n
+
+
+def bench_compute_loss(args):
+    """Train.compute_loss (/root/reference/train.py:272-309): a 375 x 1242 ground-truth map resized to
+    256 x 512 (the reference's own sizes, config.py:20-21) against the prediction.  One sample is what
+    the reference evaluates per call (twice per step, left and right: train.py:113); the batched lines
+    are the same call over B samples.  Algorithmic bytes: both maps read once."""
+    from depth_estimation_amd._lib import lib
+    L = lib()
+    for B, Ht, Wt, H, W in ((1, 375, 1242, 256, 512), (64, 375, 1242, 256, 512), (256, 375, 1242, 256, 512),
+                            (64, args.height, args.width, args.height, args.width)):
+        target = torch.rand(B, Ht, Wt, device="cuda")
+        pred = torch.rand(B, H, W, device="cuda")
+        out = torch.empty(B, 4, device="cuda")
+        nb = L.dw_compute_loss_workspace_bytes(B, H, W)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+
+        def run():  # on the current stream: the graph capture below runs on a stream of its own
+            assert L.dw_compute_loss_fwd(B, Ht, Wt, H, W, target.data_ptr(), pred.data_ptr(), out.data_ptr(), 0,
+                                         ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream) == 0
+
+        run()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+        ms = min(timed(run, args.steps, args.warmup), timed(graph.replay, args.steps, args.warmup))
+        nbytes = B * 4 * (Ht * Wt + H * W)
+        o = line("compute_loss", "samples/s", B, ms, args,
+                 f"compute_loss of ({B},{Ht},{Wt}) ground truth against ({B},{H},{W}) predictions",
+                 "compute_loss_tile_kernel", nbytes)
+        if B == 1 and not args.no_cpu_baseline:
+            from oracle.compute_loss import compute_loss as ref
+            t1, p1 = target.cpu(), pred.cpu()
+            per, n = cpu_time(lambda: ref(t1, p1), max_n=50)
+            o["cpu_baseline"] = {"value": 1 / per, "unit": "samples/s", "cores": torch.get_num_threads(),
+                                 "kind": "port", "sample": f"{n} evaluations of one sample"}
+        print(json.dumps(o), flush=True)
 
 
 def bench_metrics(args):

@@ -20,24 +20,33 @@
 //   rmse = sqrt(mean((resize(gt) - clamp(1/pred, lo, hi))^2))    train.py:311-343
 //   min(pred), max(pred) for normalize_image                     train.py:248-253
 // and normalize_image itself is the element-wise kernel at the end of the file.
+#include <algorithm>
 #include <mutex>
 
 #include "dw_common.h"
 
 namespace dw {
 
-constexpr int CL_TH = 16, CL_TW = 64, CL_NT = 256, CL_HALO = 3;
-constexpr int CL_RW = CL_TW + 2 * CL_HALO, CL_RH = CL_TH + 2 * CL_HALO, CL_R = CL_RW * CL_RH;
+// One wave owns a strip of CL_CW columns (two adjacent ones per lane) and walks down a chunk of
+// rows.  Per step it takes one row of the resized target and of the prediction, exchanges the
+// neighbouring columns through a row buffer in LDS, filters the row along x and pushes the
+// result into a window of the last seven rows that lives in registers; the filter along y, the
+// SSIM, the Sobel sums and the absolute difference all come out of registers.  Nothing but the
+// two row buffers goes through LDS, every input value is fetched once per strip (plus three
+// halo rows and columns per side), and the halo costs a row filter only.
+constexpr int CL_CW = 128, CL_HALO = 3, CL_NT = 64;
+constexpr int CL_ROWBUF = CL_CW + 2 * CL_HALO + 2;  // region columns x0-3 .. x0+130, padded
+constexpr int CL_MIN_ROWS = 8, CL_MAX_ROWS = 64;
 
 struct ClParams {
-  int B, Ht, Wt, H, W, tilesX, tilesY;
+  int B, Ht, Wt, H, W, strips, chunks, rows;
   int antialias;  // resize with the area-weighted triangle filter instead of two taps per axis
   const float* target;
   const float* pred;
-  float* part;  // [B][tiles][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
-                //                       sum (t - clamp(1/p))^2, min p, max p, unused
+  float* part;  // [B][chunks * strips][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
+                //                                sum (t - clamp(1/p))^2, min p, max p, unused
   float* out;   // [B][4 or 8]
-  float g[7];   // Gaussian taps
+  float g[4];   // Gaussian taps, centre last (the window is symmetric)
   float clamp_lo, clamp_hi;
 };
 
@@ -85,132 +94,279 @@ __device__ __forceinline__ float block_extreme(float v, float* red) {
   return v;
 }
 
-template <bool METRICS>
-__global__ __launch_bounds__(CL_NT) void compute_loss_tile_kernel(const ClParams p) {
+// MODE 0: target already has the size of the prediction; 1: two-tap bilinear resize;
+// 2: anti-aliased resize.
+template <int MODE, bool METRICS>
+__global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParams p) {
   constexpr int PS = METRICS ? 8 : 4;
-  __shared__ float s_t[CL_R];              // resized target, reflect-mapped halo
-  __shared__ float s_p[CL_R];              // prediction
-  __shared__ float s_h[5][CL_RH * CL_TW];  // row-filtered t, p, tt, pp, tp
-  __shared__ float s_red[CL_NT / kWave];
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int tY = blockIdx.x / p.tilesX, tX = blockIdx.x - tY * p.tilesX;
-  const int y00 = tY * CL_TH - CL_HALO, x00 = tX * CL_TW - CL_HALO;
+  __shared__ __attribute__((aligned(16))) float s_row[2][2][CL_ROWBUF];  // [slot][target | prediction][region column]
+  const int lane = threadIdx.x, b = blockIdx.y;
+  const int chunk = blockIdx.x / p.strips, strip = blockIdx.x - chunk * p.strips;
   const int H = p.H, W = p.W;
+  const int x0 = strip * CL_CW, y0 = chunk * p.rows, y1 = min(y0 + p.rows, H);
   const float* tg = p.target + (long)b * p.Ht * p.Wt;
   const float* pr = p.pred + (long)b * H * W;
-  const bool same = (p.Ht == H && p.Wt == W);
   const float sy = (float)p.Ht / (float)H, sx = (float)p.Wt / (float)W;
 
-  for (int i = tid; i < CL_R; i += CL_NT) {
-    const int ry = i / CL_RW, rx = i - ry * CL_RW;
-    const int y = reflect_index(y00 + ry, H), x = reflect_index(x00 + rx, W);
-    float t;
-    if (same) {
-      t = tg[(long)y * W + x];
-    } else if (p.antialias) {
-      // rows of the input first (horizontal pass), then the weighted rows (vertical pass)
-      const AaSpan ay = aa_span(y, p.Ht, sy), ax = aa_span(x, p.Wt, sx);
-      t = 0.f;
-      for (int j = 0; j < ay.n; ++j) {
-        const float* row = tg + (long)(ay.lo + j) * p.Wt + ax.lo;
-        float h = 0.f;
-        for (int k = 0; k < ax.n; ++k) h = fmaf(ax.weight(k), row[k], h);
-        t = fmaf(ay.weight(j), h, t);
+  // the lane's columns: its own two, and for the first six lanes one of the halo columns
+  // (region column c holds image column x0 - 3 + c, reflected into the image)
+  const int xa = x0 + 2 * lane;
+  const bool has_halo = lane < 2 * CL_HALO;
+  const int hc = lane < CL_HALO ? lane : CL_CW + lane;
+  const bool live_a = xa < W, live_b = xa + 1 < W;
+  const int cxa = reflect_index(min(xa, W + CL_HALO - 1), W);
+  const int cxb = reflect_index(min(xa + 1, W + CL_HALO - 1), W);
+  const int cxh = reflect_index(min(x0 - CL_HALO + hc, W + CL_HALO - 1), W);
+  // The two own columns are neighbours in memory (in either order where the image edge
+  // reflects them; columns beyond the reflection are never used): one 8-byte load each.
+  const int own = min(cxa, cxb);
+  const bool swapped = cxb < cxa;
+  // A pair of horizontal resize taps is one 8-byte load as well; at the right edge, where
+  // both taps are the last column, the pair ends there and its second value is taken twice.
+  struct PairTaps {
+    int i;     // first column of the pair
+    bool end;  // both taps are the pair's second value
+    float l0, l1;
+  };
+  PairTaps tx[3];
+  AaSpan ax[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int col = c == 0 ? cxa : (c == 1 ? cxb : cxh);
+    if (MODE == 1) {
+      const Taps t = upsample_taps(col, p.Wt, sx);
+      tx[c].end = t.i1 == t.i0;
+      tx[c].i = tx[c].end ? t.i0 - 1 : t.i0;
+      tx[c].l0 = t.l0;
+      tx[c].l1 = t.l1;
+    }
+    if (MODE == 2) ax[c] = aa_span(col, p.Wt, sx);
+  }
+
+  struct Row {
+    float2 t[3][2];  // MODE 1: tap pairs of the three columns in the two source rows;
+                     // otherwise t[0][0] = the own pair, t[2][0].x = the halo column
+    float2 q;        // prediction, own pair
+    float qh;        // prediction, halo column
+    float l0, l1;    // weights of the two source rows (MODE 1)
+  };
+  auto load2 = [](const float* ptr) __attribute__((always_inline)) {
+    float2 v;
+    __builtin_memcpy(&v, ptr, sizeof(v));  // 4-byte aligned 8-byte load
+    return v;
+  };
+  auto fetch = [&](int r) __attribute__((always_inline)) {
+    Row w;
+    const int ry = reflect_index(r, H);
+    const float* prow = pr + (long)ry * W;
+    w.q = load2(prow + own);
+    w.qh = 0.f;
+    if (has_halo) w.qh = prow[cxh];
+    w.l0 = 1.f;
+    w.l1 = 0.f;
+    if (MODE == 0) {
+      const float* trow = tg + (long)ry * W;
+      w.t[0][0] = load2(trow + own);
+      w.t[2][0].x = 0.f;
+      if (has_halo) w.t[2][0].x = trow[cxh];
+    } else if (MODE == 1) {
+      const Taps ty = upsample_taps(ry, p.Ht, sy);
+      const float* r0 = tg + (long)ty.i0 * p.Wt;
+      const float* r1 = tg + (long)ty.i1 * p.Wt;
+      w.l0 = ty.l0;
+      w.l1 = ty.l1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        w.t[c][0] = w.t[c][1] = make_float2(0.f, 0.f);
+        if (c < 2 || has_halo) {
+          w.t[c][0] = load2(r0 + tx[c].i);
+          w.t[c][1] = load2(r1 + tx[c].i);
+        }
       }
     } else {
-      const Taps ty = upsample_taps(y, p.Ht, sy), tx = upsample_taps(x, p.Wt, sx);
-      const float v00 = tg[(long)ty.i0 * p.Wt + tx.i0], v01 = tg[(long)ty.i0 * p.Wt + tx.i1];
-      const float v10 = tg[(long)ty.i1 * p.Wt + tx.i0], v11 = tg[(long)ty.i1 * p.Wt + tx.i1];
-      t = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
-    }
-    s_t[i] = t;
-    s_p[i] = pr[(long)y * W + x];
-  }
-  __syncthreads();
-
-  // rows: 7-tap Gaussian along x for every region row, core columns only
-  for (int i = tid; i < CL_RH * CL_TW; i += CL_NT) {
-    const int ry = i / CL_TW, cx = i - ry * CL_TW;
-    const int base = ry * CL_RW + cx;  // region column cx .. cx+6 is centred on core column cx
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+      // rows of the input first (horizontal pass), then the weighted rows (vertical pass)
+      const AaSpan ay = aa_span(ry, p.Ht, sy);
+      float v[3];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const float t = s_t[base + k], q = s_p[base + k], w = p.g[k];
-      a0 = fmaf(w, t, a0);
-      a1 = fmaf(w, q, a1);
-      a2 = fmaf(w, t * t, a2);
-      a3 = fmaf(w, q * q, a3);
-      a4 = fmaf(w, t * q, a4);
+      for (int c = 0; c < 3; ++c) {
+        float t = 0.f;
+        if (c < 2 || has_halo) {
+          for (int j = 0; j < ay.n; ++j) {
+            const float* row = tg + (long)(ay.lo + j) * p.Wt + ax[c].lo;
+            float h = 0.f;
+            for (int k = 0; k < ax[c].n; ++k) h = fmaf(ax[c].weight(k), row[k], h);
+            t = fmaf(ay.weight(j), h, t);
+          }
+        }
+        v[c] = t;
+      }
+      w.t[0][0] = make_float2(v[0], v[1]);
+      w.t[2][0].x = v[2];
     }
-    s_h[0][i] = a0;
-    s_h[1][i] = a1;
-    s_h[2][i] = a2;
-    s_h[3][i] = a3;
-    s_h[4][i] = a4;
-  }
-  __syncthreads();
+    return w;
+  };
+  // resized target of column c (0, 1: own; 2: halo) and the prediction, in image order
+  auto resized = [&](const Row& w, int c) __attribute__((always_inline)) {
+    if (MODE == 1) {
+      const float v00 = tx[c].end ? w.t[c][0].y : w.t[c][0].x, v01 = w.t[c][0].y;
+      const float v10 = tx[c].end ? w.t[c][1].y : w.t[c][1].x, v11 = w.t[c][1].y;
+      return w.l0 * (tx[c].l0 * v00 + tx[c].l1 * v01) + w.l1 * (tx[c].l0 * v10 + tx[c].l1 * v11);
+    }
+    if (c == 2) return w.t[2][0].x;
+    if (MODE == 2) return c ? w.t[0][0].y : w.t[0][0].x;
+    return (c == 1) != swapped ? w.t[0][0].y : w.t[0][0].x;
+  };
 
-  float sdx = 0.f, sdy = 0.f, sss = 0.f, sl1 = 0.f;
-  float sse = 0.f, pmin = INFINITY, pmax = -INFINITY;
-  for (int i = tid; i < CL_TH * CL_TW; i += CL_NT) {
-    const int cy = i / CL_TW, cx = i - cy * CL_TW;
-    const int y = y00 + CL_HALO + cy, x = x00 + CL_HALO + cx;
-    if (y >= H || x >= W) continue;
-    // columns: 7 taps along y
-    float m2 = 0.f, m1 = 0.f, e22 = 0.f, e11 = 0.f, e12 = 0.f;
+  const float g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
+  // symmetric seven-tap window over v[0..6]
+  auto gauss = [&](float v0, float v1, float v2, float v3, float v4, float v5, float v6) __attribute__((always_inline)) {
+    float a = g3 * v3;
+    a = fmaf(g2, v2 + v4, a);
+    a = fmaf(g1, v1 + v5, a);
+    return fmaf(g0, v0 + v6, a);
+  };
+
+  // The last seven rows in registers, indexed by the step's phase (the loop is unrolled seven
+  // times, so every index is a constant): row-filtered target, prediction, t^2 + p^2, t p, and
+  // the row's Sobel partials (right - left, left + 2 centre + right).
+  float win[7][6][2];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const int j = (cy + k) * CL_TW + cx;
-      const float w = p.g[k];
-      m2 = fmaf(w, s_h[0][j], m2);
-      m1 = fmaf(w, s_h[1][j], m1);
-      e22 = fmaf(w, s_h[2][j], e22);
-      e11 = fmaf(w, s_h[3][j], e11);
-      e12 = fmaf(w, s_h[4][j], e12);
-    }
-    const float s11 = e11 - m1 * m1, s22 = e22 - m2 * m2, s12 = e12 - m1 * m2;
-    const float num = (2.f * m1 * m2 + 1e-4f) * (2.f * s12 + 9e-4f);
-    const float den = (m1 * m1 + m2 * m2 + 1e-4f) * (s11 + s22 + 9e-4f);
-    const float ssim = num / (den + 1e-12f);
-    sss += fminf(fmaxf((1.f - ssim) * 0.5f, 0.f), 1.f);
-    // Sobel on the resized target, replicate border: neighbours by clamped
-    // image coordinates (the region stores in-image pixels at their own place)
-    const int ym = max(y - 1, 0) - y00, yp = min(y + 1, H - 1) - y00, yc = y - y00;
-    const int xm = max(x - 1, 0) - x00, xp = min(x + 1, W - 1) - x00, xc = x - x00;
-    const float t00 = s_t[ym * CL_RW + xm], t01 = s_t[ym * CL_RW + xc], t02 = s_t[ym * CL_RW + xp];
-    const float t10 = s_t[yc * CL_RW + xm], t12 = s_t[yc * CL_RW + xp];
-    const float t20 = s_t[yp * CL_RW + xm], t21 = s_t[yp * CL_RW + xc], t22 = s_t[yp * CL_RW + xp];
-    const float dx = ((t02 - t00) + 2.f * (t12 - t10) + (t22 - t20)) * 0.125f;
-    const float dy = ((t20 - t00) + 2.f * (t21 - t01) + (t22 - t02)) * 0.125f;
-    sdx += fabsf(dx);
-    sdy += fabsf(dy);
-    const int c = yc * CL_RW + xc;
-    sl1 += fabsf(s_t[c] - s_p[c]);
-    if (METRICS) {
-      const float q = s_p[c];
-      const float depth = fminf(fmaxf(1.0f / q, p.clamp_lo), p.clamp_hi);
-      const float e = s_t[c] - depth;
-      sse = fmaf(e, e, sse);
-      pmin = fminf(pmin, q);
-      pmax = fmaxf(pmax, q);
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) win[i][k][0] = win[i][k][1] = 0.f;
+
+  // sums per own column; a column outside the image is dropped once, at the end
+  float sdx[2] = {0.f, 0.f}, sdy[2] = {0.f, 0.f}, sss[2] = {0.f, 0.f}, sl1[2] = {0.f, 0.f};
+  float sse[2] = {0.f, 0.f}, pmin[2] = {INFINITY, INFINITY}, pmax[2] = {-INFINITY, -INFINITY};
+  const int r_last = y1 + CL_HALO - 1;
+  int r = y0 - CL_HALO;
+  Row row = fetch(r);
+  for (;;) {
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) {
+      if (r > r_last) goto done;
+      float* st = s_row[r & 1][0];
+      float* sq = s_row[r & 1][1];
+      st[2 * lane + CL_HALO] = resized(row, 0);
+      st[2 * lane + CL_HALO + 1] = resized(row, 1);
+      sq[2 * lane + CL_HALO] = swapped ? row.q.y : row.q.x;
+      sq[2 * lane + CL_HALO + 1] = swapped ? row.q.x : row.q.y;
+      if (has_halo) {
+        st[hc] = resized(row, 2);
+        sq[hc] = row.qh;
+      }
+      if (r < r_last) row = fetch(r + 1);  // in flight while this row is worked on
+      __syncthreads();
+      float a[8], q[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 va = reinterpret_cast<const float2*>(st)[lane + k];
+        const float2 vq = reinterpret_cast<const float2*>(sq)[lane + k];
+        a[2 * k] = va.x;
+        a[2 * k + 1] = va.y;
+        q[2 * k] = vq.x;
+        q[2 * k + 1] = vq.y;
+      }
+      float e[8], c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        e[k] = fmaf(a[k], a[k], q[k] * q[k]);
+        c[k] = a[k] * q[k];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        win[ph][0][j] = gauss(a[j], a[j + 1], a[j + 2], a[j + 3], a[j + 4], a[j + 5], a[j + 6]);
+        win[ph][1][j] = gauss(q[j], q[j + 1], q[j + 2], q[j + 3], q[j + 4], q[j + 5], q[j + 6]);
+        win[ph][2][j] = gauss(e[j], e[j + 1], e[j + 2], e[j + 3], e[j + 4], e[j + 5], e[j + 6]);
+        win[ph][3][j] = gauss(c[j], c[j + 1], c[j + 2], c[j + 3], c[j + 4], c[j + 5], c[j + 6]);
+        // Sobel partials of this row, replicate border in x (the row buffer is reflect-mapped)
+        const int x = xa + j;
+        const float tc = a[CL_HALO + j];
+        const float tl = (x == 0) ? tc : a[CL_HALO + j - 1];
+        const float tr = (x >= W - 1) ? tc : a[CL_HALO + j + 1];
+        win[ph][4][j] = tr - tl;
+        win[ph][5][j] = (tl + 2.f * tc) + tr;
+      }
+      if (r >= y0 && r < y1) {  // absolute difference (and the metrics) of this row
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float tv = a[CL_HALO + j], qv = q[CL_HALO + j];
+          sl1[j] += fabsf(tv - qv);
+          if (METRICS) {
+            const float depth = fminf(fmaxf(1.0f / qv, p.clamp_lo), p.clamp_hi);
+            const float d = tv - depth;
+            sse[j] = fmaf(d, d, sse[j]);
+            pmin[j] = fminf(pmin[j], qv);
+            pmax[j] = fmaxf(pmax[j], qv);
+          }
+        }
+      }
+      const int ys = r - 1;  // Sobel of the row above this one, replicate border in y
+      if (ys >= y0 && ys < y1) {
+        const int UP = (ph + 5) % 7, MID = (ph + 6) % 7, DN = ph;  // constants once unrolled
+        const int up = (ys == 0) ? MID : UP, dn = (ys == H - 1) ? MID : DN;
+        if (up == UP && dn == DN) {  // the common case on its own path: no per-value selects
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            sdx[j] += fabsf(((win[UP][4][j] + 2.f * win[MID][4][j]) + win[DN][4][j]) * 0.125f);
+            sdy[j] += fabsf((win[DN][5][j] - win[UP][5][j]) * 0.125f);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float d_up = up == UP ? win[UP][4][j] : win[MID][4][j], s_up = up == UP ? win[UP][5][j] : win[MID][5][j];
+            const float d_dn = dn == DN ? win[DN][4][j] : win[MID][4][j], s_dn = dn == DN ? win[DN][5][j] : win[MID][5][j];
+            sdx[j] += fabsf(((d_up + 2.f * win[MID][4][j]) + d_dn) * 0.125f);
+            sdy[j] += fabsf((s_dn - s_up) * 0.125f);
+          }
+        }
+      }
+      if (r - CL_HALO >= y0) {  // seven rows are in the window: SSIM of its middle row
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float m[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            m[k] = gauss(win[(ph + 1) % 7][k][j], win[(ph + 2) % 7][k][j], win[(ph + 3) % 7][k][j],
+                         win[(ph + 4) % 7][k][j], win[(ph + 5) % 7][k][j], win[(ph + 6) % 7][k][j], win[ph][k][j]);
+          const float mm = m[0] * m[1], msq = fmaf(m[0], m[0], m[1] * m[1]);
+          const float s_sum = m[2] - msq, s12 = m[3] - mm;
+          const float num = fmaf(2.f, mm, 1e-4f) * fmaf(2.f, s12, 9e-4f);
+          const float den = (msq + 1e-4f) * (s_sum + 9e-4f);
+          const float ssim = num * __builtin_amdgcn_rcpf(den + 1e-12f);
+          sss[j] += fminf(fmaxf((1.f - ssim) * 0.5f, 0.f), 1.f);
+        }
+      }
+      ++r;
     }
   }
-  float* out = p.part + ((long)b * p.tilesX * p.tilesY + blockIdx.x) * PS;
-  float t = block_sum<CL_NT>(sdx, s_red);
-  if (tid == 0) out[0] = t;
-  t = block_sum<CL_NT>(sdy, s_red);
-  if (tid == 0) out[1] = t;
-  t = block_sum<CL_NT>(sss, s_red);
-  if (tid == 0) out[2] = t;
-  t = block_sum<CL_NT>(sl1, s_red);
-  if (tid == 0) out[3] = t;
+done:
+  float* out = p.part + ((long)b * p.strips * p.chunks + blockIdx.x) * PS;
+  auto both = [&](const float* v) __attribute__((always_inline)) {
+    return wave_sum((live_a ? v[0] : 0.f) + (live_b ? v[1] : 0.f));
+  };
+  const float t_dx = both(sdx), t_dy = both(sdy), t_ss = both(sss), t_l1 = both(sl1);
+  float t_se = 0.f, lo = INFINITY, hi = -INFINITY;
   if (METRICS) {
-    t = block_sum<CL_NT>(sse, s_red);
-    if (tid == 0) out[4] = t;
-    t = block_extreme<CL_NT, false>(pmin, s_red);
-    if (tid == 0) out[5] = t;
-    t = block_extreme<CL_NT, true>(pmax, s_red);
-    if (tid == 0) out[6] = t;
+    t_se = both(sse);
+    lo = fminf(live_a ? pmin[0] : INFINITY, live_b ? pmin[1] : INFINITY);
+    hi = fmaxf(live_a ? pmax[0] : -INFINITY, live_b ? pmax[1] : -INFINITY);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, off, kWave));
+      hi = fmaxf(hi, __shfl_xor(hi, off, kWave));
+    }
+  }
+  if (lane == kSumLane) {
+    out[0] = t_dx;
+    out[1] = t_dy;
+    out[2] = t_ss;
+    out[3] = t_l1;
+    if (METRICS) {
+      out[4] = t_se;
+      out[5] = lo;
+      out[6] = hi;
+    }
   }
 }
 
@@ -220,7 +376,7 @@ __global__ __launch_bounds__(256) void compute_loss_finalize_kernel(const ClPara
   __shared__ double red[NS][256];
   __shared__ float ext[2][256];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int nt = p.tilesX * p.tilesY;
+  const int nt = p.strips * p.chunks;
   double a[NS];
   for (int k = 0; k < NS; ++k) a[k] = 0.0;
   float lo = INFINITY, hi = -INFINITY;
@@ -377,10 +533,21 @@ __global__ __launch_bounds__(NI_NT) void normalize_image_kernel(long n, int nblk
 
 using namespace dw;
 
+// Rows per chunk: as tall as leaves about `kWantWaves` waves for the launch (a strip re-filters six
+// halo rows per chunk, so taller is cheaper as long as the chip stays full).
+static int compute_loss_rows(int B, int H, int W) {
+  constexpr long kWantWaves = 4096;
+  const long strips = (W + CL_CW - 1) / CL_CW;
+  const long want_chunks = std::max<long>(1, kWantWaves / (strips * B));
+  const long rows = (H + want_chunks - 1) / want_chunks;
+  return (int)std::min<long>(std::max<long>(rows, CL_MIN_ROWS), CL_MAX_ROWS);
+}
+
 extern "C" size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t W) {
   if (B < 1 || H < 4 || W < 4) return 0;
-  const size_t tiles = (size_t)((W + CL_TW - 1) / CL_TW) * ((H + CL_TH - 1) / CL_TH);
-  return align_up(sizeof(float) * 8 * tiles * B, 256);  // enough for the metrics variant too
+  // the largest number of (strip, chunk) partials any choice of the chunk height can need
+  const size_t parts = (size_t)((W + CL_CW - 1) / CL_CW) * ((H + CL_MIN_ROWS - 1) / CL_MIN_ROWS);
+  return align_up(sizeof(float) * 8 * parts * B, 256);  // enough for the metrics variant too
 }
 
 template <bool METRICS>
@@ -391,6 +558,7 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   if (flags & ~DW_CL_FLAG_ANTIALIAS) return DW_ERR_ARG;
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
+  if ((long)H * W > (1l << 28) || (long)Ht * Wt > (1l << 28)) return DW_ERR_SHAPE;
   if (workspace_bytes < dw_compute_loss_workspace_bytes(B, H, W) || ((uintptr_t)workspace & 255))
     return DW_ERR_WORKSPACE;
   ClParams p{};
@@ -399,8 +567,9 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   p.Wt = Wt;
   p.H = H;
   p.W = W;
-  p.tilesX = (W + CL_TW - 1) / CL_TW;
-  p.tilesY = (H + CL_TH - 1) / CL_TH;
+  p.rows = compute_loss_rows(B, H, W);
+  p.strips = (W + CL_CW - 1) / CL_CW;
+  p.chunks = (H + p.rows - 1) / p.rows;
   p.antialias = (flags & DW_CL_FLAG_ANTIALIAS) ? 1 : 0;
   p.target = target;
   p.pred = pred;
@@ -414,9 +583,15 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
     g[k] = exp(-(x * x) / (2.0 * 1.5 * 1.5));
     sum += g[k];
   }
-  for (int k = 0; k < 7; ++k) p.g[k] = (float)(g[k] / sum);
+  for (int k = 0; k < 4; ++k) p.g[k] = (float)(g[k] / sum);
   hipStream_t st = (hipStream_t)stream;
-  compute_loss_tile_kernel<METRICS><<<dim3(p.tilesX * p.tilesY, B), CL_NT, 0, st>>>(p);
+  const dim3 grid(p.strips * p.chunks, B);
+  if (Ht == H && Wt == W)
+    compute_loss_strip_kernel<0, METRICS><<<grid, CL_NT, 0, st>>>(p);
+  else if (p.antialias)
+    compute_loss_strip_kernel<2, METRICS><<<grid, CL_NT, 0, st>>>(p);
+  else
+    compute_loss_strip_kernel<1, METRICS><<<grid, CL_NT, 0, st>>>(p);
   compute_loss_finalize_kernel<METRICS><<<B, 256, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
