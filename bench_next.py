@@ -113,7 +113,7 @@ def bench_compute_loss(args):
         nbytes = B * 4 * (Ht * Wt + H * W)
         o = line("compute_loss", "samples/s", B, ms, args,
                  f"compute_loss of ({B},{Ht},{Wt}) ground truth against ({B},{H},{W}) predictions",
-                 "compute_loss_tile_kernel", nbytes)
+                 "compute_loss_strip_kernel", nbytes)
         if B == 1 and not args.no_cpu_baseline:
             from oracle.compute_loss import compute_loss as ref
             t1, p1 = target.cpu(), pred.cpu()
@@ -145,7 +145,7 @@ def bench_metrics(args):
     ms = timed(fused, args.steps, args.warmup)
     nbytes = B * H * W * (8 + 8)   # loss+metrics: two maps in; normalize: one in, one out
     o = line("loss_and_metrics", "samples/s", B, ms, args,
-             f"compute_loss + rmse + extrema + normalize_image on ({B},1,{H},{W})", "compute_loss_tile_kernel",
+             f"compute_loss + rmse + extrema + normalize_image on ({B},1,{H},{W})", "compute_loss_strip_kernel",
              nbytes)
     if not args.no_cpu_baseline:
         from oracle.compute_loss import compute_loss_terms

@@ -1,4 +1,4 @@
-// Train.compute_loss(target, pred) of the reference as one tiled kernel plus a
+// Train.compute_loss(target, pred) of the reference as one strip kernel plus a
 // per-sample finalisation (/root/reference/train.py:272-309), forward only as
 // there (the reference body runs under no_grad, train.py:274).
 //
@@ -13,9 +13,11 @@
 //
 // SSIM follows kornia's definition: 7x7 Gaussian window (sigma 1.5, normalised),
 // reflect border, C1 = 0.01^2, C2 = 0.03^2, ssim = num / (den + 1e-12).  The
-// window is applied separably (rows, then columns) from an LDS tile.
+// window is applied separably: along x on each row as it arrives, along y over
+// the last seven filtered rows, which a lane keeps in registers.  The sum of the
+// two variances is filtered as one plane (t^2 + p^2): SSIM needs only their sum.
 //
-// The METRICS variant adds, from the same tile, what the reference's evaluation
+// The METRICS variant adds, from the same pass, what the reference's evaluation
 // code derives from the same two tensors in separate passes:
 //   rmse = sqrt(mean((resize(gt) - clamp(1/pred, lo, hi))^2))    train.py:311-343
 //   min(pred), max(pred) for normalize_image                     train.py:248-253
@@ -36,7 +38,7 @@ namespace dw {
 // halo rows and columns per side), and the halo costs a row filter only.
 constexpr int CL_CW = 128, CL_HALO = 3, CL_NT = 64;
 constexpr int CL_ROWBUF = CL_CW + 2 * CL_HALO + 2;  // region columns x0-3 .. x0+130, padded
-constexpr int CL_MIN_ROWS = 8, CL_MAX_ROWS = 64;
+constexpr int CL_MIN_ROWS = 2, CL_MAX_ROWS = 64;
 
 struct ClParams {
   int B, Ht, Wt, H, W, strips, chunks, rows;
@@ -217,7 +219,13 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
     return (c == 1) != swapped ? w.t[0][0].y : w.t[0][0].x;
   };
 
-  const float g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
+  // The taps in vector registers: an instruction with a scalar-register operand holds the
+  // vector pipe for longer than one without, and the taps go into every second instruction.
+  float g0, g1, g2, g3;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(g0) : "s"(p.g[0]));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(g1) : "s"(p.g[1]));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(g2) : "s"(p.g[2]));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(g3) : "s"(p.g[3]));
   // symmetric seven-tap window over v[0..6]
   auto gauss = [&](float v0, float v1, float v2, float v3, float v4, float v5, float v6) __attribute__((always_inline)) {
     float a = g3 * v3;
@@ -536,7 +544,7 @@ using namespace dw;
 // Rows per chunk: as tall as leaves about `kWantWaves` waves for the launch (a strip re-filters six
 // halo rows per chunk, so taller is cheaper as long as the chip stays full).
 static int compute_loss_rows(int B, int H, int W) {
-  constexpr long kWantWaves = 4096;
+  constexpr long kWantWaves = 3072;  // three per SIMD; measured flat between two and four
   const long strips = (W + CL_CW - 1) / CL_CW;
   const long want_chunks = std::max<long>(1, kWantWaves / (strips * B));
   const long rows = (H + want_chunks - 1) / want_chunks;
@@ -559,8 +567,6 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
   if ((long)H * W > (1l << 28) || (long)Ht * Wt > (1l << 28)) return DW_ERR_SHAPE;
-  if (workspace_bytes < dw_compute_loss_workspace_bytes(B, H, W) || ((uintptr_t)workspace & 255))
-    return DW_ERR_WORKSPACE;
   ClParams p{};
   p.B = B;
   p.Ht = Ht;
@@ -570,6 +576,10 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   p.rows = compute_loss_rows(B, H, W);
   p.strips = (W + CL_CW - 1) / CL_CW;
   p.chunks = (H + p.rows - 1) / p.rows;
+  // one set of partial sums per (strip, chunk) and sample; dw_compute_loss_workspace_bytes is
+  // the bound of this over every chunk height
+  if (workspace_bytes < sizeof(float) * 8 * (size_t)p.strips * p.chunks * B || ((uintptr_t)workspace & 255))
+    return DW_ERR_WORKSPACE;
   p.antialias = (flags & DW_CL_FLAG_ANTIALIAS) ? 1 : 0;
   p.target = target;
   p.pred = pred;
@@ -613,7 +623,7 @@ extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, in
 }
 
 // ---------------------------------------------------------------- allocation-free entry point
-// The per-tile partial sums of dw_compute_loss_fwd live in a fixed device array
+// The partial sums of dw_compute_loss_fwd (one set per strip and chunk) live in a fixed device array
 // of this library instead of a caller workspace.  Every GPU the library runs on
 // holds its own copy of the array at its own address until the process ends;
 // `scratch` itself is only a host-side handle of the symbol (not a device
@@ -645,12 +655,13 @@ extern "C" int dw_compute_loss_fwd_static(int32_t B, int32_t Ht, int32_t Wt, int
                                           void* stream) {
   if (!target || !pred || !out) return DW_ERR_NULL;
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
-  const size_t need = dw_compute_loss_workspace_bytes(B, H, W);
-  if (need == 0) return DW_ERR_SHAPE;
+  // what this call writes: one set of partial sums per (strip, chunk) of every sample
+  const int rows = compute_loss_rows(B, H, W);
+  const size_t need = sizeof(float) * 8 * (size_t)((W + CL_CW - 1) / CL_CW) * ((H + rows - 1) / rows) * B;
   if (need > DW_STATIC_SCRATCH_BYTES) return DW_ERR_TOO_LARGE;
   void* ptr = static_scratch_ptr();
   if (!ptr) return DW_ERR_LAUNCH;
-  // every partial the finalisation reads is written by the tile kernel of the same call:
+  // every partial the finalisation reads is written by the strip kernel of the same call:
   // nothing in the array has to start at zero
   return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, flags, ptr,
                                     DW_STATIC_SCRATCH_BYTES, stream);

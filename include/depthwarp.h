@@ -166,7 +166,8 @@ DW_API int dw_photometric_bwd_color(const dw_desc* desc,
  *            torchvision's, whose default for tensors is a plain two-tap
  *            bilinear resize in some releases and the anti-aliased (area
  *            weighted triangle filter) one in others; the flag selects the latter
- *   workspace: dw_compute_loss_workspace_bytes(B,H,W) bytes
+ *   workspace: dw_compute_loss_workspace_bytes(B,H,W) bytes (an upper bound; a
+ *            call uses 32 bytes per sample, 128-column strip and row chunk)
  * ------------------------------------------------------------------------- */
 #define DW_CL_FLAG_ANTIALIAS 1
 
@@ -179,11 +180,13 @@ DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
 /* dw_compute_loss_fwd for callers that cannot allocate or bring a workspace
  * (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  No counterpart in the reference; same kernels and results as
- * dw_compute_loss_fwd.  The per-tile partial sums live in a fixed device array
+ * dw_compute_loss_fwd.  The partial sums live in a fixed device array
  * inside the library (DW_STATIC_SCRATCH_BYTES per GPU the library runs on, held
  * until the process ends); the call allocates and frees nothing.
- *   - the problem must fit: dw_compute_loss_workspace_bytes(B, H, W) <=
- *     DW_STATIC_SCRATCH_BYTES (e.g. B <= 256 at 256 x 512), else DW_ERR_TOO_LARGE;
+ *   - the problem must fit: the call keeps 32 bytes per sample, 128-column strip
+ *     and chunk of rows (chunks are 2 to 64 rows tall, taller the more samples
+ *     there are) and refuses with DW_ERR_TOO_LARGE what exceeds
+ *     DW_STATIC_SCRATCH_BYTES (at 256 x 512: more than 2048 samples);
  *   - all calls on one GPU share that GPU's array: calls that overlap in time on
  *     one GPU (different streams or threads) race -- serialise them, or use
  *     dw_compute_loss_fwd with workspaces of their own;

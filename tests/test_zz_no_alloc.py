@@ -57,9 +57,10 @@ def test_static_scratch_entry_point_refuses_what_does_not_fit_and_python_wrapper
     from depth_estimation_amd import _lib
     from depth_estimation_amd.loss import compute_loss_into, compute_loss_terms
     lib = _lib.lib()
-    # 8 floats per 16 x 64 tile and sample: 2048 x 2048 at B = 16 needs 2 MiB of partials
-    B, H, W = 16, 2048, 2048
-    assert lib.dw_compute_loss_workspace_bytes(B, H, W) > _lib.DW_STATIC_SCRATCH_BYTES
+    # 8 floats per 128-column strip, chunk of at most 64 rows and sample: 64 x 4096 x 2048 needs
+    # 2 MiB of partial sums
+    B, H, W = 64, 4096, 2048
+    assert 32 * (W // 128) * (H // 64) * B > _lib.DW_STATIC_SCRATCH_BYTES
     x = torch.zeros(1, device="cuda")
     rc = lib.dw_compute_loss_fwd_static(B, H, W, H, W, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, None)
     assert rc == -6 and b"too large" in lib.dw_strerror(rc)
