@@ -378,51 +378,66 @@ done:
   }
 }
 
+// One block per sample adds the partial sums in double, in a fixed order.  The partials come
+// from other compute units' caches: every thread has its few loads in flight at once (16-byte
+// loads, unrolled), since the kernel is nothing but their latency.
 template <bool METRICS>
 __global__ __launch_bounds__(256) void compute_loss_finalize_kernel(const ClParams p) {
   constexpr int PS = METRICS ? 8 : 4, NS = METRICS ? 5 : 4;  // partial stride, number of sums
-  __shared__ double red[NS][256];
-  __shared__ float ext[2][256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double red[NS][256 / kWave];
+  __shared__ float ext[2][256 / kWave];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   const int nt = p.strips * p.chunks;
   double a[NS];
   for (int k = 0; k < NS; ++k) a[k] = 0.0;
   float lo = INFINITY, hi = -INFINITY;
+#pragma unroll 4
   for (int t = tid; t < nt; t += 256) {
-    const float* src = p.part + ((long)b * nt + t) * PS;
-    for (int k = 0; k < NS; ++k) a[k] += (double)src[k];
+    const float4* src = reinterpret_cast<const float4*>(p.part + ((long)b * nt + t) * PS);
+    const float4 u = src[0];
+    a[0] += (double)u.x;
+    a[1] += (double)u.y;
+    a[2] += (double)u.z;
+    a[3] += (double)u.w;
     if (METRICS) {
-      lo = fminf(lo, src[5]);
-      hi = fmaxf(hi, src[6]);
+      const float4 v = src[1];
+      a[NS - 1] += (double)v.x;
+      lo = fminf(lo, v.y);
+      hi = fmaxf(hi, v.z);
     }
   }
-  for (int k = 0; k < NS; ++k) red[k][tid] = a[k];
-  ext[0][tid] = lo;
-  ext[1][tid] = hi;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    for (int k = 0; k < NS; ++k) a[k] += __shfl_xor(a[k], off, kWave);
+    lo = fminf(lo, __shfl_xor(lo, off, kWave));
+    hi = fmaxf(hi, __shfl_xor(hi, off, kWave));
+  }
+  if (lane == 0) {
+    for (int k = 0; k < NS; ++k) red[k][wid] = a[k];
+    ext[0][wid] = lo;
+    ext[1][wid] = hi;
+  }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
-      for (int k = 0; k < NS; ++k) red[k][tid] += red[k][tid + o];
-      ext[0][tid] = fminf(ext[0][tid], ext[0][tid + o]);
-      ext[1][tid] = fmaxf(ext[1][tid], ext[1][tid + o]);
-    }
-    __syncthreads();
-  }
   if (tid == 0) {
+    for (int w = 1; w < 256 / kWave; ++w) {
+      for (int k = 0; k < NS; ++k) a[k] += red[k][w];
+      lo = fminf(lo, ext[0][w]);
+      hi = fmaxf(hi, ext[1][w]);
+    }
     const double n = (double)p.H * p.W;
-    const float mx = (float)(red[0][0] / n), my = (float)(red[1][0] / n);
+    const float mx = (float)(a[0] / n), my = (float)(a[1] / n);
     const float smooth = mx * expf(mx) + my * expf(my);
-    const float ssim_term = 1.f - (float)(red[2][0] / n);
-    const float l1 = (float)(red[3][0] / n);
+    const float ssim_term = 1.f - (float)(a[2] / n);
+    const float l1 = (float)(a[3] / n);
     float* o = p.out + (long)b * PS;
     o[0] = 0.75f * ssim_term + 0.20f * l1 + 0.15f * smooth;
     o[1] = ssim_term;
     o[2] = l1;
     o[3] = smooth;
     if (METRICS) {
-      o[4] = sqrtf((float)(red[NS - 1][0] / n));
-      o[5] = ext[0][0];
-      o[6] = ext[1][0];
+      o[4] = sqrtf((float)(a[NS - 1] / n));
+      o[5] = lo;
+      o[6] = hi;
       o[7] = 0.f;
     }
   }
