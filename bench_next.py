@@ -114,6 +114,19 @@ def bench_compute_loss(args):
         o = line("compute_loss", "samples/s", B, ms, args,
                  f"compute_loss of ({B},{Ht},{Wt}) ground truth against ({B},{H},{W}) predictions",
                  "compute_loss_strip_kernel", nbytes)
+        if B == 1:
+            # the call as the reference makes it (train.py:113): float64 ground truth, Python entry
+            # point, result left on the device; wall clock per call, host side included
+            from depth_estimation_amd.loss import compute_loss
+            t64 = target.double()
+            for _ in range(20):
+                compute_loss(t64, pred)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                compute_loss(t64, pred)
+            torch.cuda.synchronize()
+            o["python_call_us"] = 1e6 * (time.perf_counter() - t0) / 200
         if B == 1 and not args.no_cpu_baseline:
             from oracle.compute_loss import compute_loss as ref
             t1, p1 = target.cpu(), pred.cpu()
