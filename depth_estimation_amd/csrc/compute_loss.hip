@@ -582,6 +582,8 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
   if ((long)H * W > (1l << 28) || (long)Ht * Wt > (1l << 28)) return DW_ERR_SHAPE;
+  // the horizontal taps of the resize are fetched as pairs of neighbouring columns
+  if ((Ht != H || Wt != W) && Wt < 2) return DW_ERR_SHAPE;
   ClParams p{};
   p.B = B;
   p.Ht = Ht;

@@ -48,6 +48,26 @@ def test_antialiased_resize_matches_oracle(B, Ht, Wt, H, W):
         assert not torch.allclose(got["loss"], plain["loss"], rtol=1e-3, atol=0)
 
 
+@pytest.mark.parametrize("B,Ht,Wt,H,W", [(1, 4, 4, 4, 4), (2, 9, 300, 9, 129), (1, 7, 5, 6, 260), (3, 5, 2, 11, 7),
+                                          (1, 130, 127, 130, 127), (2, 64, 1, 64, 1 + 3)])
+def test_edge_shapes_match_oracle(B, Ht, Wt, H, W):
+    """Smallest sizes the reflect border allows, widths around the 128-column strip (a strip with a
+    single live column, an odd width whose last pair straddles the edge), two-column sources."""
+    from oracle.compute_loss import compute_loss_terms as ref_terms
+    from depth_estimation_amd import _lib
+    from depth_estimation_amd.loss import compute_loss_terms
+    target, pred = _inputs(B, Ht, Wt, H, W, seed=3 * H + W)
+    if Wt == 1:  # a one-column source cannot be resized by pairs of columns: refused, not mis-read
+        with pytest.raises(_lib.DepthwarpError):
+            compute_loss_terms(target.cuda(), pred.cuda())
+        return
+    for aa in (False, True):
+        ref = ref_terms(target, pred, antialias=aa)
+        got = compute_loss_terms(target.cuda(), pred.cuda(), antialias=aa)
+        for k in ("loss", "ssim_term", "l1", "smooth"):
+            assert torch.allclose(got[k].cpu(), ref[k], rtol=RTOL, atol=1e-7), (aa, k, got[k], ref[k])
+
+
 def test_batched_equals_per_sample_loop():
     from depth_estimation_amd.loss import compute_loss
     target, pred = _inputs(4, 96, 320, 64, 128, seed=9)
