@@ -159,7 +159,9 @@ DW_API int dw_photometric_bwd_color(const dw_desc* desc,
  * Batched: sample b of the result equals the reference's batch-1 call on
  * sample b.
  *   target   (B,1,Ht,Wt)  ground truth, resized to (H,W) inside (bilinear,
- *            align_corners=False; train.py:276)
+ *            align_corners=False; train.py:276); H, W >= 4 (reflect border of
+ *            the 7x7 window), Wt >= 2 when it differs from (H,W), H*W and
+ *            Ht*Wt <= 2^28, B <= 65535; otherwise DW_ERR_SHAPE
  *   pred     (B,1,H,W)
  *   out      (B,4) floats: loss, ssim_term, l1, smooth   (train.py:299-307)
  *   flags    0, or DW_CL_FLAG_ANTIALIAS: the resize of train.py:276 is
