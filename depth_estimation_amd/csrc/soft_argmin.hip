@@ -52,6 +52,15 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // wave-uniform byte offset in a scalar register (the disparity plane) and one
 // 32-bit per-lane byte offset (the pixel).  No 64-bit per-load address
 // registers, which is what lets a lane keep its whole column set in registers.
+// Cache policy of the volume accesses: 2 = non-temporal.  The cost volume is read once and its
+// gradient written once, 500 MB each: marking them as streaming keeps them from displacing
+// each other in the caches (measured: forward 94 -> 90 us, backward 206 -> 202 us).
+#ifndef SA_LOAD_AUX
+#define SA_LOAD_AUX 2
+#endif
+#ifndef SA_STORE_AUX
+#define SA_STORE_AUX 2
+#endif
 typedef unsigned sa_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned sa_u4 __attribute__((ext_vector_type(4)));
 using sa_rsrc = buf_rsrc;
@@ -65,29 +74,29 @@ typedef float sa_f4 __attribute__((ext_vector_type(4)));
 template <int VEC>
 __device__ __forceinline__ void load_vec(sa_rsrc r, unsigned lane_off, unsigned plane_off, float* v) {
   if constexpr (VEC == 4) {
-    const sa_f4 t = __builtin_bit_cast(sa_f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, plane_off, 0));
+    const sa_f4 t = __builtin_bit_cast(sa_f4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, plane_off, SA_LOAD_AUX));
     v[0] = t.x;
     v[1] = t.y;
     v[2] = t.z;
     v[3] = t.w;
   } else if constexpr (VEC == 2) {
-    const sa_f2 t = __builtin_bit_cast(sa_f2, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, plane_off, 0));
+    const sa_f2 t = __builtin_bit_cast(sa_f2, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, plane_off, SA_LOAD_AUX));
     v[0] = t.x;
     v[1] = t.y;
   } else {
-    v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, plane_off, 0));
+    v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, plane_off, SA_LOAD_AUX));
   }
 }
 template <int VEC>
 __device__ __forceinline__ void store_vec(sa_rsrc r, unsigned lane_off, unsigned plane_off, const float* v) {
   if constexpr (VEC == 4) {
     const sa_f4 t = {v[0], v[1], v[2], v[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sa_u4, t), r, lane_off, plane_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sa_u4, t), r, lane_off, plane_off, SA_STORE_AUX);
   } else if constexpr (VEC == 2) {
     const sa_f2 t = {v[0], v[1]};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sa_u2, t), r, lane_off, plane_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sa_u2, t), r, lane_off, plane_off, SA_STORE_AUX);
   } else {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), r, lane_off, plane_off, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), r, lane_off, plane_off, SA_STORE_AUX);
   }
 }
 
