@@ -21,7 +21,10 @@
 //
 // "Last wins", "first of the group" and "minimum of the group" are computed
 // with integer max / min atomics on the compacted point index and on an
-// order-preserving integer image of z: independent of execution order.
+// order-preserving integer image of z: independent of execution order.  The
+// three values of a group share one 16-byte record (one cache line per point
+// instead of three), and the map itself is written sparsely: zero fill, then
+// one thread per kept point decides the pixel it is the last point of.
 #include "dw_common.h"
 
 namespace dw {
@@ -41,9 +44,13 @@ struct LidarParams {
   double* zbuf;           // (B, n_max)  z of point i
   int* blk_count;         // (B, nblk)   kept points per block, then exclusive offsets
   int* last;              // (B, H*W)    largest compacted index landing on the pixel
-  int* count;             // (B, H*W+1)  points per key (key + 1 indexes the array)
-  int* first;             // (B, H*W+1)  smallest compacted index of the key
-  long long* minz;        // (B, H*W+1)  smallest ordered(z) of the key
+  struct KeyRec* rec;     // (B, H*W+1)  per key (key + 1 indexes the array)
+};
+
+struct __attribute__((aligned(16))) KeyRec {
+  long long minz;  // smallest ordered(z) of the key's points
+  int first;       // smallest compacted index of the key
+  int count;       // points with the key
 };
 
 // order-preserving map double -> signed 64-bit integer (and back)
@@ -61,9 +68,11 @@ __global__ __launch_bounds__(LD_NT) void lidar_init_kernel(const LidarParams p) 
   const long i = (long)blockIdx.x * LD_NT + threadIdx.x;
   if (i < hw) p.last[b * hw + i] = -1;
   if (i < hw + 1) {
-    p.count[b * (hw + 1) + i] = 0;
-    p.first[b * (hw + 1) + i] = 0x7fffffff;
-    p.minz[b * (hw + 1) + i] = 0x7fffffffffffffffLL;
+    KeyRec r;
+    r.minz = 0x7fffffffffffffffLL;
+    r.first = 0x7fffffff;
+    r.count = 0;
+    p.rec[b * (hw + 1) + i] = r;  // one 16-byte store
   }
 }
 
@@ -157,34 +166,37 @@ __global__ __launch_bounds__(LD_NT) void lidar_scatter_kernel(const LidarParams 
     o[2] = z;
     const int key1 = y * (p.W - 1) + x;  // sub2ind key + 1, in [0, H*W - H]
     atomicMax(&p.last[b * hw + loc], j);
-    atomicAdd(&p.count[b * (hw + 1) + key1], 1);
-    atomicMin(&p.first[b * (hw + 1) + key1], j);
-    atomicMin(&p.minz[b * (hw + 1) + key1], ordered(z));
+    KeyRec* r = &p.rec[b * (hw + 1) + key1];
+    atomicAdd(&r->count, 1);
+    atomicMin(&r->first, j);
+    atomicMin(&r->minz, ordered(z));
   }
 }
 
+// One thread per kept point j: the last point of a pixel writes the pixel.  (Pixels
+// without a point keep the zero fill.)
 __global__ __launch_bounds__(LD_NT) void lidar_depth_kernel(const LidarParams p) {
   const int b = blockIdx.y;
   const long hw = (long)p.H * p.W;
-  const long loc = (long)blockIdx.x * LD_NT + threadIdx.x;
-  if (loc >= hw) return;
-  const int y = (int)(loc / p.W), x = (int)(loc - (long)y * p.W);
+  const int j = blockIdx.x * LD_NT + threadIdx.x;
+  if (j >= p.n_valid[b]) return;
   const double* pts = p.pts_im + (long)b * p.n_max * 3;
-  double d = 0.0;
-  const int last = p.last[b * hw + loc];
-  if (last >= 0) d = pts[(long)last * 3 + 2];
+  const int x = (int)pts[(long)j * 3 + 0], y = (int)pts[(long)j * 3 + 1];
+  const long loc = (long)y * p.W + x;
+  if (p.last[b * hw + loc] != j) return;
+  double d = pts[(long)j * 3 + 2];
   // the only group that can write here is the one with this pixel's key, and
   // it does so if its first point lies on this pixel
-  const long key1 = (long)y * (p.W - 1) + x;
-  if (p.count[b * (hw + 1) + key1] > 1) {
-    const double* f = pts + (long)p.first[b * (hw + 1) + key1] * 3;
-    if ((int)f[0] == x && (int)f[1] == y) d = unordered(p.minz[b * (hw + 1) + key1]);
+  const KeyRec r = p.rec[b * (hw + 1) + (long)y * (p.W - 1) + x];
+  if (r.count > 1) {
+    const double* f = pts + (long)r.first * 3;
+    if ((int)f[0] == x && (int)f[1] == y) d = unordered(r.minz);
   }
   p.depth[b * hw + loc] = (d < 0.0) ? 0.0 : d;
 }
 
 struct LidarLayout {
-  size_t loc, zbuf, blk, last, count, first, minz, total;
+  size_t loc, zbuf, blk, last, rec, total;
 };
 
 static LidarLayout lidar_layout(int B, int n_max, int H, int W) {
@@ -197,12 +209,10 @@ static LidarLayout lidar_layout(int B, int n_max, int H, int W) {
     return at;
   };
   L.zbuf = take(sizeof(double) * B * n_max);
-  L.minz = take(sizeof(long long) * B * (hw + 1));
+  L.rec = take(sizeof(KeyRec) * B * (hw + 1));
   L.loc = take(sizeof(int) * B * n_max);
   L.blk = take(sizeof(int) * B * nblk);
   L.last = take(sizeof(int) * B * hw);
-  L.count = take(sizeof(int) * B * (hw + 1));
-  L.first = take(sizeof(int) * B * (hw + 1));
   L.total = o;
   return L;
 }
@@ -237,8 +247,8 @@ extern "C" int dw_lidar_project(int32_t B, int32_t n_max, int32_t H, int32_t W, 
   p.points = points; p.n_points = n_points; p.P = P;
   p.pts_im = pts_im; p.n_valid = n_valid; p.depth = depth;
   p.loc = (int*)(ws + L.loc); p.zbuf = (double*)(ws + L.zbuf); p.blk_count = (int*)(ws + L.blk);
-  p.last = (int*)(ws + L.last); p.count = (int*)(ws + L.count); p.first = (int*)(ws + L.first);
-  p.minz = (long long*)(ws + L.minz);
+  p.last = (int*)(ws + L.last);
+  p.rec = (KeyRec*)(ws + L.rec);
   hipStream_t st = (hipStream_t)stream;
   const long hw = (long)H * W;
   const dim3 gpix((unsigned)((hw + 1 + LD_NT - 1) / LD_NT), B), gpts(p.nblk, B);
@@ -246,6 +256,7 @@ extern "C" int dw_lidar_project(int32_t B, int32_t n_max, int32_t H, int32_t W, 
   lidar_project_kernel<<<gpts, LD_NT, 0, st>>>(p);
   lidar_scan_kernel<<<B, LD_NT, 0, st>>>(p);
   lidar_scatter_kernel<<<gpts, LD_NT, 0, st>>>(p);
-  lidar_depth_kernel<<<gpix, LD_NT, 0, st>>>(p);
+  if (hipMemsetAsync(depth, 0, sizeof(double) * (size_t)B * hw, st) != hipSuccess) return DW_ERR_LAUNCH;
+  lidar_depth_kernel<<<gpts, LD_NT, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
