@@ -21,10 +21,11 @@
 //
 // "Last wins", "first of the group" and "minimum of the group" are computed
 // with integer max / min atomics on the compacted point index and on an
-// order-preserving integer image of z: independent of execution order.  The
-// three values of a group share one 16-byte record (one cache line per point
-// instead of three), and the map itself is written sparsely: zero fill, then
-// one thread per kept point decides the pixel it is the last point of.
+// order-preserving integer image of z: independent of execution order.  They
+// are kept per pixel, in one 16-byte record (one cache line per point): a group is a
+// pixel, or the two pixels (y, W-1) and (y+1, 0), whose records are combined when the map
+// is written.  The map itself is written sparsely: zero fill, then one thread per kept
+// point decides the pixel it is the last point of.
 #include "dw_common.h"
 
 namespace dw {
@@ -43,14 +44,13 @@ struct LidarParams {
   int* loc;               // (B, n_max)  pixel index of point i, -1 if dropped
   double* zbuf;           // (B, n_max)  z of point i
   int* blk_count;         // (B, nblk)   kept points per block, then exclusive offsets
-  int* last;              // (B, H*W)    largest compacted index landing on the pixel
-  struct KeyRec* rec;     // (B, H*W+1)  per key (key + 1 indexes the array)
+  struct PixRec* rec;     // (B, H*W)
 };
 
-struct __attribute__((aligned(16))) KeyRec {
-  long long minz;  // smallest ordered(z) of the key's points
-  int first;       // smallest compacted index of the key
-  int count;       // points with the key
+struct __attribute__((aligned(16))) PixRec {
+  long long minz;  // smallest ordered(z) of the pixel's points
+  int first;       // smallest compacted index landing on the pixel
+  int last;        // largest one (-1: none)
 };
 
 // order-preserving map double -> signed 64-bit integer (and back)
@@ -66,13 +66,12 @@ __global__ __launch_bounds__(LD_NT) void lidar_init_kernel(const LidarParams p) 
   const int b = blockIdx.y;
   const long hw = (long)p.H * p.W;
   const long i = (long)blockIdx.x * LD_NT + threadIdx.x;
-  if (i < hw) p.last[b * hw + i] = -1;
-  if (i < hw + 1) {
-    KeyRec r;
+  if (i < hw) {
+    PixRec r;
     r.minz = 0x7fffffffffffffffLL;
     r.first = 0x7fffffff;
-    r.count = 0;
-    p.rec[b * (hw + 1) + i] = r;  // one 16-byte store
+    r.last = -1;
+    p.rec[b * hw + i] = r;  // one 16-byte store
   }
 }
 
@@ -164,10 +163,8 @@ __global__ __launch_bounds__(LD_NT) void lidar_scatter_kernel(const LidarParams 
     o[0] = (double)x;
     o[1] = (double)y;
     o[2] = z;
-    const int key1 = y * (p.W - 1) + x;  // sub2ind key + 1, in [0, H*W - H]
-    atomicMax(&p.last[b * hw + loc], j);
-    KeyRec* r = &p.rec[b * (hw + 1) + key1];
-    atomicAdd(&r->count, 1);
+    PixRec* r = &p.rec[b * hw + loc];
+    atomicMax(&r->last, j);
     atomicMin(&r->first, j);
     atomicMin(&r->minz, ordered(z));
   }
@@ -183,20 +180,32 @@ __global__ __launch_bounds__(LD_NT) void lidar_depth_kernel(const LidarParams p)
   const double* pts = p.pts_im + (long)b * p.n_max * 3;
   const int x = (int)pts[(long)j * 3 + 0], y = (int)pts[(long)j * 3 + 1];
   const long loc = (long)y * p.W + x;
-  if (p.last[b * hw + loc] != j) return;
+  const PixRec* rec = p.rec + b * hw;
+  const PixRec r = rec[loc];
+  if (r.last != j) return;
   double d = pts[(long)j * 3 + 2];
-  // the only group that can write here is the one with this pixel's key, and
-  // it does so if its first point lies on this pixel
-  const KeyRec r = p.rec[b * (hw + 1) + (long)y * (p.W - 1) + x];
-  if (r.count > 1) {
-    const double* f = pts + (long)r.first * 3;
-    if ((int)f[0] == x && (int)f[1] == y) d = unordered(r.minz);
+  // The group of this pixel's key y * (W - 1) + x - 1: the pixel itself and, at the ends of a
+  // row, the pixel that shares the key ((y, W-1) with (y+1, 0)).  A group of more than one
+  // point writes its smallest z at the pixel of its first point.
+  int first = r.first, last = r.last;
+  long long minz = r.minz;
+  long other = -1;
+  if (x == p.W - 1 && y + 1 < p.H) other = loc + 1;
+  if (x == 0 && y > 0) other = loc - 1;
+  if (other >= 0) {
+    const PixRec o = rec[other];
+    if (o.last >= 0) {
+      first = min(first, o.first);
+      last = max(last, o.last);
+      minz = min(minz, o.minz);
+    }
   }
+  if (first != last && first == r.first) d = unordered(minz);
   p.depth[b * hw + loc] = (d < 0.0) ? 0.0 : d;
 }
 
 struct LidarLayout {
-  size_t loc, zbuf, blk, last, rec, total;
+  size_t loc, zbuf, blk, rec, total;
 };
 
 static LidarLayout lidar_layout(int B, int n_max, int H, int W) {
@@ -209,10 +218,9 @@ static LidarLayout lidar_layout(int B, int n_max, int H, int W) {
     return at;
   };
   L.zbuf = take(sizeof(double) * B * n_max);
-  L.rec = take(sizeof(KeyRec) * B * (hw + 1));
+  L.rec = take(sizeof(PixRec) * B * hw);
   L.loc = take(sizeof(int) * B * n_max);
   L.blk = take(sizeof(int) * B * nblk);
-  L.last = take(sizeof(int) * B * hw);
   L.total = o;
   return L;
 }
@@ -247,11 +255,10 @@ extern "C" int dw_lidar_project(int32_t B, int32_t n_max, int32_t H, int32_t W, 
   p.points = points; p.n_points = n_points; p.P = P;
   p.pts_im = pts_im; p.n_valid = n_valid; p.depth = depth;
   p.loc = (int*)(ws + L.loc); p.zbuf = (double*)(ws + L.zbuf); p.blk_count = (int*)(ws + L.blk);
-  p.last = (int*)(ws + L.last);
-  p.rec = (KeyRec*)(ws + L.rec);
+  p.rec = (PixRec*)(ws + L.rec);
   hipStream_t st = (hipStream_t)stream;
   const long hw = (long)H * W;
-  const dim3 gpix((unsigned)((hw + 1 + LD_NT - 1) / LD_NT), B), gpts(p.nblk, B);
+  const dim3 gpix((unsigned)((hw + LD_NT - 1) / LD_NT), B), gpts(p.nblk, B);
   lidar_init_kernel<<<gpix, LD_NT, 0, st>>>(p);
   lidar_project_kernel<<<gpts, LD_NT, 0, st>>>(p);
   lidar_scan_kernel<<<B, LD_NT, 0, st>>>(p);
