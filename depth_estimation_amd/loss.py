@@ -8,7 +8,8 @@ train.py:274; the caller marks the scalar `requires_grad_` itself, train.py:114)
 
 The reference is hard-wired to batch 1 (`view(1, 1, H, W)`, train.py:277-279).
 Here a batch is allowed: sample b of the result equals the reference call on
-sample b; a batch of one returns a 0-dim tensor like the reference.
+sample b (to float32 rounding: the grouping of an image's partial sums depends on
+the batch size); a batch of one returns a 0-dim tensor like the reference.
 """
 from __future__ import annotations
 

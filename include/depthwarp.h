@@ -157,7 +157,8 @@ DW_API int dw_photometric_bwd_color(const dw_desc* desc,
  * Reference loss: Train.compute_loss(target, pred), train.py:272-309, forward
  * only as in the reference (its body runs under no_grad, train.py:274).
  * Batched: sample b of the result equals the reference's batch-1 call on
- * sample b.
+ * sample b (to float32 rounding: how the partial sums of an image are grouped
+ * depends on the batch size; a given call is bitwise reproducible).
  *   target   (B,1,Ht,Wt)  ground truth, resized to (H,W) inside (bilinear,
  *            align_corners=False; train.py:276); H, W >= 4 (reflect border of
  *            the 7x7 window), Wt >= 2 when it differs from (H,W), H*W and

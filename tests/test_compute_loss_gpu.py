@@ -77,6 +77,22 @@ def test_batched_equals_per_sample_loop():
     assert torch.equal(batched, single)
 
 
+def test_large_batch_equals_per_sample_calls_to_rounding_and_is_reproducible():
+    """At 64 x (375x1242 -> 256x512) the row chunks are taller than in a batch of one, so the
+    partial sums are grouped differently: equal to rounding, and bitwise equal run to run."""
+    from depth_estimation_amd.loss import compute_loss_terms
+    target, pred = _inputs(64, 375, 1242, 256, 512, seed=21)
+    t, p = target.cuda(), pred.cuda()
+    a = compute_loss_terms(t, p)
+    b = compute_loss_terms(t, p)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    for i in (0, 17, 63):
+        one = compute_loss_terms(t[i:i + 1], p[i:i + 1])
+        for k in a:
+            assert torch.allclose(a[k][i:i + 1], one[k], rtol=2e-6, atol=0), (i, k)
+
+
 def test_float64_target_like_reference():
     from oracle.compute_loss import compute_loss as ref
     from depth_estimation_amd.loss import compute_loss
