@@ -29,8 +29,20 @@ def _as_b1hw(name: str, t: Tensor) -> Tensor:
     return t
 
 
-@torch.library.custom_op("depthwarp::compute_loss_fwd", mutates_args=())
-def compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
+# Partial-sum workspaces, one per (device, stream): a call's kernels run on the current
+# stream, so calls that could overlap never share one.  A few KB each; grown on demand.
+_workspaces = {}
+
+
+def _workspace(device: torch.device, stream: int, nbytes: int) -> Tensor:
+    key = (device.index, stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
     """target (B,1,Ht,Wt), pred (B,1,H,W), float32 -> (B,4): loss, ssim_term, l1, smooth."""
     if not (target.is_cuda and pred.is_cuda):
         raise _lib.DepthwarpError("compute_loss: expected ROCm device tensors "
@@ -44,15 +56,30 @@ def compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> T
     nbytes = lib.dw_compute_loss_workspace_bytes(B, H, W)
     if nbytes == 0:
         raise _lib.DepthwarpError(f"compute_loss: unsupported shape B={B} H={H} W={W}")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
-    out = torch.empty((B, 4), dtype=torch.float32, device=pred.device)
-    with torch.cuda.device(pred.device):
+    dev = pred.device
+    out = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    other = torch.cuda.current_device() != dev.index
+    if other:  # the library launches on the current device
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(dev)
+    try:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = _workspace(dev, stream, nbytes)
         rc = lib.dw_compute_loss_fwd(B, target.shape[2], target.shape[3], H, W,
                                      target.data_ptr(), pred.data_ptr(), out.data_ptr(),
-                                     _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0, ws.data_ptr(), nbytes,
-                                     torch.cuda.current_stream(pred.device).cuda_stream)
+                                     _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0, ws.data_ptr(), ws.numel(),
+                                     stream)
+    finally:
+        if other:
+            torch.cuda.set_device(prev)
     _lib.check(rc, "dw_compute_loss_fwd")
     return out
+
+
+@torch.library.custom_op("depthwarp::compute_loss_fwd", mutates_args=())
+def compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
+    """The same as a torch operator (traceable: `register_fake` below)."""
+    return _compute_loss_fwd(target, pred, antialias)
 
 
 @compute_loss_fwd.register_fake
@@ -60,17 +87,26 @@ def _(target, pred, antialias=False):
     return torch.empty((pred.shape[0], 4), dtype=torch.float32, device=pred.device)
 
 
-def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: int = None,
-                       antialias: bool = False):
-    """Per-sample terms as a dict of (B,) tensors: loss, ssim_term, l1, smooth."""
+def _terms(target: Tensor, pred: Tensor, height, width, antialias: bool) -> Tensor:
+    """(B,4) tensor of loss, ssim_term, l1, smooth per sample."""
     with torch.no_grad():
         pred = _as_b1hw("pred", pred)
         target = _as_b1hw("target", target)
         if height is not None and tuple(pred.shape[-2:]) != (height, width):
             # the reference's `pred.view(1, 1, H, W)` raises on a size mismatch
             raise RuntimeError(f"pred has shape {tuple(pred.shape)}, expected (*,1,{height},{width})")
+        # eager calls skip the operator dispatcher; under torch.compile the registered operator
+        # is what gets traced
+        fwd = compute_loss_fwd if torch.compiler.is_compiling() else _compute_loss_fwd
         # the reference hands over a float64 target (NumPy pipeline); compute in float32
-        out = compute_loss_fwd(target.float(), pred.float(), antialias)
+        return fwd(target if target.dtype == torch.float32 else target.float(),
+                   pred if pred.dtype == torch.float32 else pred.float(), antialias)
+
+
+def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: int = None,
+                       antialias: bool = False):
+    """Per-sample terms as a dict of (B,) tensors: loss, ssim_term, l1, smooth."""
+    out = _terms(target, pred, height, width, antialias)
     return {"loss": out[:, 0], "ssim_term": out[:, 1], "l1": out[:, 2], "smooth": out[:, 3]}
 
 
@@ -84,8 +120,8 @@ def compute_loss(target: Tensor, pred: Tensor, height: int = None, width: int = 
     some releases and the anti-aliased one in others; the reference pins no
     version): False = two taps per axis, True = area-weighted triangle filter
     (`F.interpolate(..., antialias=True)`)."""
-    loss = compute_loss_terms(target, pred, height, width, antialias)["loss"]
-    return loss[0] if loss.numel() == 1 else loss
+    out = _terms(target, pred, height, width, antialias)
+    return out[0, 0] if out.shape[0] == 1 else out[:, 0]
 
 
 def compute_loss_into(out: Tensor, target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
