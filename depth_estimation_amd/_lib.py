@@ -20,6 +20,7 @@ DW_FLAG_TILE_KERNEL_ONLY = 1
 DW_FLAG_NO_TAIL_SPLIT = 2
 DW_FLAG_COLOR_GRAD = 4
 DW_CL_FLAG_ANTIALIAS = 1
+DW_CL_FLAG_TARGET_F64 = 2
 DW_STATIC_SCRATCH_BYTES = 1 << 20
 
 

@@ -43,7 +43,7 @@ constexpr int CL_MIN_ROWS = 2, CL_MAX_ROWS = 64;
 struct ClParams {
   int B, Ht, Wt, H, W, strips, chunks, rows;
   int antialias;  // resize with the area-weighted triangle filter instead of two taps per axis
-  const float* target;
+  const void* target;  // float32, or float64 for the kernels instantiated with TT = double
   const float* pred;
   float* part;  // [B][chunks * strips][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
                 //                                sum (t - clamp(1/p))^2, min p, max p, unused
@@ -97,8 +97,10 @@ __device__ __forceinline__ float block_extreme(float v, float* red) {
 }
 
 // MODE 0: target already has the size of the prediction; 1: two-tap bilinear resize;
-// 2: anti-aliased resize.
-template <int MODE, bool METRICS>
+// 2: anti-aliased resize.  TT: element type of the target in memory -- the reference hands over
+// float64 ground truth (NumPy pipeline) and computes in float32 after a cast; a double target is
+// rounded to float32 value by value as it is read, which is that cast without a pass of its own.
+template <int MODE, bool METRICS, typename TT>
 __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParams p) {
   constexpr int PS = METRICS ? 8 : 4;
   __shared__ __attribute__((aligned(16))) float s_row[2][2][CL_ROWBUF];  // [slot][target | prediction][region column]
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
   const int chunk = blockIdx.x / p.strips, strip = blockIdx.x - chunk * p.strips;
   const int H = p.H, W = p.W;
   const int x0 = strip * CL_CW, y0 = chunk * p.rows, y1 = min(y0 + p.rows, H);
-  const float* tg = p.target + (long)b * p.Ht * p.Wt;
+  const TT* tg = static_cast<const TT*>(p.target) + (long)b * p.Ht * p.Wt;
   const float* pr = p.pred + (long)b * H * W;
   const float sy = (float)p.Ht / (float)H, sx = (float)p.Wt / (float)W;
 
@@ -145,8 +147,11 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
     if (MODE == 2) ax[c] = aa_span(col, p.Wt, sx);
   }
 
+  struct T2 {
+    TT x, y;
+  };
   struct Row {
-    float2 t[3][2];  // MODE 1: tap pairs of the three columns in the two source rows;
+    T2 t[3][2];      // MODE 1: tap pairs of the three columns in the two source rows;
                      // otherwise t[0][0] = the own pair, t[2][0].x = the halo column
     float2 q;        // prediction, own pair
     float qh;        // prediction, halo column
@@ -155,6 +160,11 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
   auto load2 = [](const float* ptr) __attribute__((always_inline)) {
     float2 v;
     __builtin_memcpy(&v, ptr, sizeof(v));  // 4-byte aligned 8-byte load
+    return v;
+  };
+  auto load2t = [](const TT* ptr) __attribute__((always_inline)) {
+    T2 v;
+    __builtin_memcpy(&v, ptr, sizeof(v));  // element-aligned load of two neighbours
     return v;
   };
   auto fetch = [&](int r) __attribute__((always_inline)) {
@@ -167,22 +177,22 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
     w.l0 = 1.f;
     w.l1 = 0.f;
     if (MODE == 0) {
-      const float* trow = tg + (long)ry * W;
-      w.t[0][0] = load2(trow + own);
-      w.t[2][0].x = 0.f;
+      const TT* trow = tg + (long)ry * W;
+      w.t[0][0] = load2t(trow + own);
+      w.t[2][0].x = 0;
       if (has_halo) w.t[2][0].x = trow[cxh];
     } else if (MODE == 1) {
       const Taps ty = upsample_taps(ry, p.Ht, sy);
-      const float* r0 = tg + (long)ty.i0 * p.Wt;
-      const float* r1 = tg + (long)ty.i1 * p.Wt;
+      const TT* r0 = tg + (long)ty.i0 * p.Wt;
+      const TT* r1 = tg + (long)ty.i1 * p.Wt;
       w.l0 = ty.l0;
       w.l1 = ty.l1;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        w.t[c][0] = w.t[c][1] = make_float2(0.f, 0.f);
+        w.t[c][0].x = w.t[c][0].y = w.t[c][1].x = w.t[c][1].y = 0;
         if (c < 2 || has_halo) {
-          w.t[c][0] = load2(r0 + tx[c].i);
-          w.t[c][1] = load2(r1 + tx[c].i);
+          w.t[c][0] = load2t(r0 + tx[c].i);
+          w.t[c][1] = load2t(r1 + tx[c].i);
         }
       }
     } else {
@@ -194,29 +204,31 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
         float t = 0.f;
         if (c < 2 || has_halo) {
           for (int j = 0; j < ay.n; ++j) {
-            const float* row = tg + (long)(ay.lo + j) * p.Wt + ax[c].lo;
+            const TT* row = tg + (long)(ay.lo + j) * p.Wt + ax[c].lo;
             float h = 0.f;
-            for (int k = 0; k < ax[c].n; ++k) h = fmaf(ax[c].weight(k), row[k], h);
+            for (int k = 0; k < ax[c].n; ++k) h = fmaf(ax[c].weight(k), (float)row[k], h);
             t = fmaf(ay.weight(j), h, t);
           }
         }
         v[c] = t;
       }
-      w.t[0][0] = make_float2(v[0], v[1]);
-      w.t[2][0].x = v[2];
+      w.t[0][0].x = (TT)v[0];
+      w.t[0][0].y = (TT)v[1];
+      w.t[2][0].x = (TT)v[2];
     }
     return w;
   };
   // resized target of column c (0, 1: own; 2: halo) and the prediction, in image order
   auto resized = [&](const Row& w, int c) __attribute__((always_inline)) {
     if (MODE == 1) {
-      const float v00 = tx[c].end ? w.t[c][0].y : w.t[c][0].x, v01 = w.t[c][0].y;
-      const float v10 = tx[c].end ? w.t[c][1].y : w.t[c][1].x, v11 = w.t[c][1].y;
+      const float a0 = (float)w.t[c][0].x, a1 = (float)w.t[c][0].y, b0 = (float)w.t[c][1].x, b1 = (float)w.t[c][1].y;
+      const float v00 = tx[c].end ? a1 : a0, v01 = a1;
+      const float v10 = tx[c].end ? b1 : b0, v11 = b1;
       return w.l0 * (tx[c].l0 * v00 + tx[c].l1 * v01) + w.l1 * (tx[c].l0 * v10 + tx[c].l1 * v11);
     }
-    if (c == 2) return w.t[2][0].x;
-    if (MODE == 2) return c ? w.t[0][0].y : w.t[0][0].x;
-    return (c == 1) != swapped ? w.t[0][0].y : w.t[0][0].x;
+    if (c == 2) return (float)w.t[2][0].x;
+    if (MODE == 2) return (float)(c ? w.t[0][0].y : w.t[0][0].x);
+    return (float)((c == 1) != swapped ? w.t[0][0].y : w.t[0][0].x);
   };
 
   // The taps in vector registers: an instruction with a scalar-register operand holds the
@@ -575,10 +587,10 @@ extern "C" size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t 
 
 template <bool METRICS>
 static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                               const float* target, const float* pred, float clamp_lo, float clamp_hi,
+                               const void* target, const float* pred, float clamp_lo, float clamp_hi,
                                float* out, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
   if (!target || !pred || !out || !workspace) return DW_ERR_NULL;
-  if (flags & ~DW_CL_FLAG_ANTIALIAS) return DW_ERR_ARG;
+  if (flags & ~(DW_CL_FLAG_ANTIALIAS | DW_CL_FLAG_TARGET_F64)) return DW_ERR_ARG;
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
   if ((long)H * W > (1l << 28) || (long)Ht * Wt > (1l << 28)) return DW_ERR_SHAPE;
@@ -613,25 +625,29 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   for (int k = 0; k < 4; ++k) p.g[k] = (float)(g[k] / sum);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(p.strips * p.chunks, B);
-  if (Ht == H && Wt == W)
-    compute_loss_strip_kernel<0, METRICS><<<grid, CL_NT, 0, st>>>(p);
-  else if (p.antialias)
-    compute_loss_strip_kernel<2, METRICS><<<grid, CL_NT, 0, st>>>(p);
-  else
-    compute_loss_strip_kernel<1, METRICS><<<grid, CL_NT, 0, st>>>(p);
+  const int mode = (Ht == H && Wt == W) ? 0 : (p.antialias ? 2 : 1);
+  if (flags & DW_CL_FLAG_TARGET_F64) {
+    if (mode == 0) compute_loss_strip_kernel<0, METRICS, double><<<grid, CL_NT, 0, st>>>(p);
+    if (mode == 1) compute_loss_strip_kernel<1, METRICS, double><<<grid, CL_NT, 0, st>>>(p);
+    if (mode == 2) compute_loss_strip_kernel<2, METRICS, double><<<grid, CL_NT, 0, st>>>(p);
+  } else {
+    if (mode == 0) compute_loss_strip_kernel<0, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
+    if (mode == 1) compute_loss_strip_kernel<1, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
+    if (mode == 2) compute_loss_strip_kernel<2, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
+  }
   compute_loss_finalize_kernel<METRICS><<<B, 256, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
 
 extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                                   const float* target, const float* pred, float* out, int32_t flags,
+                                   const void* target, const float* pred, float* out, int32_t flags,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, flags, workspace,
                                     workspace_bytes, stream);
 }
 
 extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                                           const float* target, const float* pred, float clamp_min,
+                                           const void* target, const float* pred, float clamp_min,
                                            float clamp_max, float* out, int32_t flags, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   if (!(clamp_min <= clamp_max)) return DW_ERR_ARG;
@@ -668,7 +684,7 @@ void* static_scratch_ptr() {
 }  // namespace
 
 extern "C" int dw_compute_loss_fwd_static(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                                          const float* target, const float* pred, float* out, int32_t flags,
+                                          const void* target, const float* pred, float* out, int32_t flags,
                                           void* stream) {
   if (!target || !pred || !out) return DW_ERR_NULL;
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;

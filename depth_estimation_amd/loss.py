@@ -43,10 +43,16 @@ def _workspace(device: torch.device, stream: int, nbytes: int) -> Tensor:
 
 
 def _compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:
-    """target (B,1,Ht,Wt), pred (B,1,H,W), float32 -> (B,4): loss, ssim_term, l1, smooth."""
+    """target (B,1,Ht,Wt) float32 or float64, pred (B,1,H,W) float32 -> (B,4): loss, ssim_term,
+    l1, smooth.  A float64 target is rounded to float32 inside the kernel as it is read."""
     if not (target.is_cuda and pred.is_cuda):
         raise _lib.DepthwarpError("compute_loss: expected ROCm device tensors "
                                   "(the HIP kernels have no CPU path)")
+    if target.dtype not in (torch.float32, torch.float64) or pred.dtype != torch.float32:
+        raise TypeError(f"compute_loss: expected a float32 / float64 target and a float32 prediction, "
+                        f"got {target.dtype} and {pred.dtype}")
+    flags = (_lib.DW_CL_FLAG_ANTIALIAS if antialias else 0) | \
+            (_lib.DW_CL_FLAG_TARGET_F64 if target.dtype == torch.float64 else 0)
     B, _, H, W = pred.shape
     if target.shape[0] != B:
         raise RuntimeError("compute_loss: target and pred disagree on the batch size")
@@ -67,8 +73,7 @@ def _compute_loss_fwd(target: Tensor, pred: Tensor, antialias: bool = False) -> 
         ws = _workspace(dev, stream, nbytes)
         rc = lib.dw_compute_loss_fwd(B, target.shape[2], target.shape[3], H, W,
                                      target.data_ptr(), pred.data_ptr(), out.data_ptr(),
-                                     _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0, ws.data_ptr(), ws.numel(),
-                                     stream)
+                                     flags, ws.data_ptr(), ws.numel(), stream)
     finally:
         if other:
             torch.cuda.set_device(prev)
@@ -98,9 +103,11 @@ def _terms(target: Tensor, pred: Tensor, height, width, antialias: bool) -> Tens
         # eager calls skip the operator dispatcher; under torch.compile the registered operator
         # is what gets traced
         fwd = compute_loss_fwd if torch.compiler.is_compiling() else _compute_loss_fwd
-        # the reference hands over a float64 target (NumPy pipeline); compute in float32
-        return fwd(target if target.dtype == torch.float32 else target.float(),
-                   pred if pred.dtype == torch.float32 else pred.float(), antialias)
+        # the reference hands over a float64 target (NumPy pipeline): the kernel reads it as it is
+        # and rounds to float32 on the way in; anything else is cast to float32 first
+        if target.dtype not in (torch.float32, torch.float64):
+            target = target.float()
+        return fwd(target, pred if pred.dtype == torch.float32 else pred.float(), antialias)
 
 
 def compute_loss_terms(target: Tensor, pred: Tensor, height: int = None, width: int = None,

@@ -159,13 +159,15 @@ DW_API int dw_photometric_bwd_color(const dw_desc* desc,
  * Batched: sample b of the result equals the reference's batch-1 call on
  * sample b (to float32 rounding: how the partial sums of an image are grouped
  * depends on the batch size; a given call is bitwise reproducible).
- *   target   (B,1,Ht,Wt)  ground truth, resized to (H,W) inside (bilinear,
+ *   target   (B,1,Ht,Wt)  ground truth, float32 (float64 with
+ *            DW_CL_FLAG_TARGET_F64), resized to (H,W) inside (bilinear,
  *            align_corners=False; train.py:276); H, W >= 4 (reflect border of
  *            the 7x7 window), Wt >= 2 when it differs from (H,W), H*W and
  *            Ht*Wt <= 2^28, B <= 65535; otherwise DW_ERR_SHAPE
  *   pred     (B,1,H,W)
  *   out      (B,4) floats: loss, ssim_term, l1, smooth   (train.py:299-307)
- *   flags    0, or DW_CL_FLAG_ANTIALIAS: the resize of train.py:276 is
+ *   flags    0, or a combination of DW_CL_FLAG_TARGET_F64 and
+ *            DW_CL_FLAG_ANTIALIAS: the resize of train.py:276 is
  *            torchvision's, whose default for tensors is a plain two-tap
  *            bilinear resize in some releases and the anti-aliased (area
  *            weighted triangle filter) one in others; the flag selects the latter
@@ -173,11 +175,15 @@ DW_API int dw_photometric_bwd_color(const dw_desc* desc,
  *            call uses 32 bytes per sample, 128-column strip and row chunk)
  * ------------------------------------------------------------------------- */
 #define DW_CL_FLAG_ANTIALIAS 1
+/* `target` points to float64 values (what the reference's NumPy pipeline hands
+ * over, load_dataset.py:69-77): each is rounded to float32 as it is read, which
+ * is the `.float()` cast of the float32 path without a pass of its own. */
+#define DW_CL_FLAG_TARGET_F64 2
 
 DW_API size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
 
 DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                        const float* target, const float* pred, float* out, int32_t flags,
+                        const void* target, const float* pred, float* out, int32_t flags,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw_compute_loss_fwd for callers that cannot allocate or bring a workspace
@@ -197,7 +203,7 @@ DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
  *     that first call outside stream capture. */
 #define DW_STATIC_SCRATCH_BYTES (1u << 20)
 DW_API int dw_compute_loss_fwd_static(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                               const float* target, const float* pred, float* out, int32_t flags,
+                               const void* target, const float* pred, float* out, int32_t flags,
                                void* stream);
 
 /* The same pass, additionally producing the evaluation metrics the reference
@@ -209,7 +215,7 @@ DW_API int dw_compute_loss_fwd_static(int32_t B, int32_t Ht, int32_t Wt, int32_t
  *   out      (B,8) floats: loss, ssim_term, l1, smooth, rmse, pred_min, pred_max, 0
  */
 DW_API int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
-                                const float* target, const float* pred, float clamp_min,
+                                const void* target, const float* pred, float clamp_min,
                                 float clamp_max, float* out, int32_t flags, void* workspace,
                                 size_t workspace_bytes, void* stream);
 

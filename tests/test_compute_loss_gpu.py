@@ -102,6 +102,35 @@ def test_float64_target_like_reference():
     assert not got.requires_grad
 
 
+@pytest.mark.parametrize("B,Ht,Wt,H,W", [(2, 375, 1242, 256, 512), (1, 64, 129, 64, 129), (2, 31, 45, 50, 70)])
+def test_float64_target_is_read_in_place_and_equals_the_cast(B, Ht, Wt, H, W):
+    """A float64 target goes to the kernel as it is (flag DW_CL_FLAG_TARGET_F64) and is rounded
+    to float32 value by value on the way in: bit-identical to casting first, for every resize
+    mode and for the metrics entry point."""
+    from depth_estimation_amd import _lib
+    from depth_estimation_amd.loss import compute_loss_terms
+    target, pred = _inputs(B, Ht, Wt, H, W, seed=Ht)
+    t64 = (target.double() + torch.rand(B, Ht, Wt, dtype=torch.float64) * 1e-9).cuda()   # not float32-representable
+    p = pred.cuda()
+    for aa in (False, True):
+        a = compute_loss_terms(t64, p, antialias=aa)
+        b = compute_loss_terms(t64.float(), p, antialias=aa)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (aa, k)
+    lib = _lib.lib()
+    n = lib.dw_compute_loss_workspace_bytes(B, H, W)
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    outs = []
+    for t, flags in ((t64, _lib.DW_CL_FLAG_TARGET_F64), (t64.float(), 0)):
+        out = torch.empty(B, 8, device="cuda")
+        rc = lib.dw_compute_loss_metrics_fwd(B, Ht, Wt, H, W, t.data_ptr(), (p + 1e-3).data_ptr(), 1e-3, 128.0,
+                                             out.data_ptr(), flags, ws.data_ptr(), n,
+                                             torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(out[:, :7].clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_shape_mismatch_raises():
     from depth_estimation_amd.loss import compute_loss
     with pytest.raises(RuntimeError):

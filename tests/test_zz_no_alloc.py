@@ -65,7 +65,7 @@ def test_static_scratch_entry_point_refuses_what_does_not_fit_and_python_wrapper
     rc = lib.dw_compute_loss_fwd_static(B, H, W, H, W, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, None)
     assert rc == -6 and b"too large" in lib.dw_strerror(rc)
     assert lib.dw_compute_loss_fwd_static(1, 8, 8, 8, 8, None, None, None, 0, None) == -1
-    assert lib.dw_compute_loss_fwd_static(1, 8, 8, 8, 8, x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, None) == -5
+    assert lib.dw_compute_loss_fwd_static(1, 8, 8, 8, 8, x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, None) == -5
     g = torch.Generator().manual_seed(1)
     target, pred = torch.rand(2, 1, 96, 320, generator=g).cuda(), torch.rand(2, 1, 64, 128, generator=g).cuda()
     out = torch.empty(2, 4, device="cuda")
