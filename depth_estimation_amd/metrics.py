@@ -39,8 +39,11 @@ def _scalar_if_single(t: Tensor) -> Tensor:
 @torch.library.custom_op("depthwarp::compute_loss_metrics_fwd", mutates_args=())
 def _loss_metrics(target: Tensor, pred: Tensor, clamp_min: float, clamp_max: float,
                   antialias: bool = False) -> Tensor:
-    """target (B,1,Ht,Wt), pred (B,1,H,W) -> (B,8)."""
+    """target (B,1,Ht,Wt) float32 or float64 (read in place, rounded to float32 by the kernel),
+    pred (B,1,H,W) float32 -> (B,8)."""
     _need_cuda(target, pred)
+    if target.dtype not in (torch.float32, torch.float64) or pred.dtype != torch.float32:
+        raise TypeError(f"expected a float32 / float64 target and a float32 prediction, got {target.dtype}, {pred.dtype}")
     B, _, H, W = pred.shape
     if target.shape[0] != B:
         raise RuntimeError("target and pred disagree on the batch size")
@@ -54,7 +57,8 @@ def _loss_metrics(target: Tensor, pred: Tensor, clamp_min: float, clamp_max: flo
     with torch.cuda.device(pred.device):
         rc = lib.dw_compute_loss_metrics_fwd(B, target.shape[2], target.shape[3], H, W, target.data_ptr(),
                                              pred.data_ptr(), clamp_min, clamp_max, out.data_ptr(),
-                                             _lib.DW_CL_FLAG_ANTIALIAS if antialias else 0,
+                                             (_lib.DW_CL_FLAG_ANTIALIAS if antialias else 0) |
+                                             (_lib.DW_CL_FLAG_TARGET_F64 if target.dtype == torch.float64 else 0),
                                              ws.data_ptr(), nbytes, _stream(pred))
     _lib.check(rc, "dw_compute_loss_metrics_fwd")
     return out
@@ -70,8 +74,10 @@ def compute_loss_and_metrics(target: Tensor, pred: Tensor, maxdisp: float = MAXD
     """One pass: dict of (B,) tensors loss, ssim_term, l1, smooth (train.py:272-309),
     rmse (train.py:311-343, one side) and pred_min / pred_max (train.py:250-251)."""
     with torch.no_grad():
-        out = _loss_metrics(_as_b1hw("target", target).float(), _as_b1hw("pred", pred).float(),
-                            1e-3, float(maxdisp), antialias)
+        target = _as_b1hw("target", target)
+        if target.dtype not in (torch.float32, torch.float64):
+            target = target.float()   # a float64 ground truth (the reference's) is read as it is
+        out = _loss_metrics(target, _as_b1hw("pred", pred).float(), 1e-3, float(maxdisp), antialias)
     names = ("loss", "ssim_term", "l1", "smooth", "rmse", "pred_min", "pred_max")
     return {k: out[:, i] for i, k in enumerate(names)}
 
