@@ -89,3 +89,20 @@ def test_one_rank_under_the_launcher_runs_the_collectives_over_rccl():
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 12
     d = _run_launched(["--mode", "train", "--steps", "3", "--warmup", "1", "--net-width", "16"])
     assert d["n_gpus"] == 1 and d["config"]["mode"] == "train"
+
+
+def test_secondary_lines_carry_the_same_fields():
+    """bench_next.py prints one line per workload with the fields of the contract line."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_next.py"), "--only", "compute_loss", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 4
+    for d in lines:
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        r = d["roofline"]
+        assert r["kernel"] == "compute_loss_strip_kernel" and 0 < r["frac"] < 1
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert lines[0]["python_call_us"] > 0
