@@ -11,7 +11,7 @@
 // Backward arithmetic uses explicit fmaf and fast reciprocals where it helps.
 //
 // Launch sequence of one training step:
-//   forward : photo_tile_kernel<GRAD> -> smooth_kernel -> loss_finalize_kernel
+//   forward : smooth_kernel (+ depth maps) -> photo_tile_kernel<GRAD> -> loss_finalize_kernel
 //   backward: backward_kernel (pose blocks + disparity-map blocks)
 // photo_tile_kernel<true> does the whole per-pixel backward at unit upstream
 // gradient while the tile is still on chip and leaves, per scale, the gradient
@@ -103,6 +103,7 @@ struct PhotoParams {
   int tilesX, tilesY;  // of the kernel being launched
   int n_full;          // blocks [0, n_full) run every scale of one tile; the rest one scale each
   int vec4;            // every scale's width is a multiple of 4 and every map pointer 16-byte aligned
+  int du_px, du_nblk;  // depth maps: pixels per thread (4 or 1) and blocks per sample
   // (H >> s) / H and (W >> s) / W as the float32 quotients the up-sampling formula uses: the same
   // for every thread, so the host divides once instead of every lane of every block
   float rsy[DW_MAX_SCALES], rsx[DW_MAX_SCALES];
@@ -117,6 +118,7 @@ struct PhotoParams {
   // workspace sections
   float* tile_loss;  // [B][tiles][4]
   float* tile_dP;    // [B][tiles][S][24]
+  float* depth_up;   // [S][B][H][W]            depth from the up-sampled disparity of every scale
   float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
   float* gxout;      // [S][B][2][3][H][W]      d loss / d (warped colour of frame f), unit upstream; optional
   float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
@@ -392,6 +394,76 @@ __device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
 #define DW_STAMP(k)
 #endif
 
+// ------------------------------------------------------------ depth of every scale
+// depth_up[s][b][y][x] = 1 / (min_disp + range * up(disp[s])(y, x)): the bilinear up-sampling of
+// every scale's disparity to full resolution and its inversion, once per pixel.  The tile kernel
+// needs these values for its whole region (1.46 pixels per pixel it is responsible for); done
+// here they cost one streaming pass instead of a latency-bound burst of 39 gathered taps and
+// twelve exact divisions per thread at the start of every tile.
+// It has no launch of its own: its blocks ride behind the blocks of the smoothness kernel,
+// which precedes the tile kernel and is as short (two short launches cost more than their work).
+constexpr int DU_NT = 256;
+// PX pixels of a row per thread (4 when the width allows 16-byte stores, else 1); all taps of a
+// thread are loaded before the first is used.  `blk`: block of sample `b`.
+template <int PX>
+__device__ __forceinline__ void depth_up_block(const PhotoParams& p, int b, int blk) {
+  const int H = p.H, W = p.W;
+  const int i = (blk * DU_NT + threadIdx.x) * PX;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  // (one scale at a time would need half the registers, which also bound the smoothness blocks
+  // of the launch; measured 2 us slower than having every tap in flight)
+  float v[DW_MAX_SCALES][PX][4], wx0[DW_MAX_SCALES][PX], wx1[DW_MAX_SCALES][PX], wy0[DW_MAX_SCALES], wy1[DW_MAX_SCALES];
+#pragma unroll
+  for (int s = 0; s < DW_MAX_SCALES; ++s) {
+    if (s < p.S) {
+      const int hs = H >> s, ws = W >> s;
+      const float* d = p.disp[s] + (long)b * hs * ws;
+      const Taps ty = upsample_taps(y, hs, p.rsy[s]);
+      wy0[s] = ty.l0;
+      wy1[s] = ty.l1;
+#pragma unroll
+      for (int k = 0; k < PX; ++k) {
+        if (s == 0) {  // not up-sampled
+          v[s][k][0] = v[s][k][1] = v[s][k][2] = v[s][k][3] = d[(long)y * ws + x + k];
+          wx0[s][k] = 1.f, wx1[s][k] = 0.f;
+        } else {
+          const Taps tx = upsample_taps(x + k, ws, p.rsx[s]);
+          v[s][k][0] = d[ty.i0 * ws + tx.i0];
+          v[s][k][1] = d[ty.i0 * ws + tx.i1];
+          v[s][k][2] = d[ty.i1 * ws + tx.i0];
+          v[s][k][3] = d[ty.i1 * ws + tx.i1];
+          wx0[s][k] = tx.l0, wx1[s][k] = tx.l1;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < DW_MAX_SCALES; ++s) {
+    if (s < p.S) {
+      float out[PX];
+#pragma unroll
+      for (int k = 0; k < PX; ++k) {
+        float du = v[s][k][0];
+        if (s > 0) {  // the association of upsampled_disp
+          const float top = wx0[s][k] * v[s][k][0] + wx1[s][k] * v[s][k][1];
+          const float bot = wx0[s][k] * v[s][k][2] + wx1[s][k] * v[s][k][3];
+          du = wy0[s] * top + wy1[s] * bot;
+        }
+        const float dsp = kMinDisp + kDispRange * du;
+        out[k] = div_by(1.0f, dsp, div_rcp(dsp));  // 1 / dsp
+      }
+      float* o = p.depth_up + ((long)s * p.B + b) * H * W + i;
+      if (PX == 4) {
+        *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < PX; ++k) o[k] = out[k];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------ the tile kernel
 // GRAD: with the per-pixel backward.  CGRAD (needs GRAD): also store the
 // adjoint of the warped colours of both frames into p.gxout.
@@ -472,24 +544,15 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
                            uniform_ptr(p.color[2] + (long)b * 3 * plane)};
   // Every global load of the prologue is issued before the first one is used
   // (nothing else is live yet, so registers are plentiful): all region pixels
-  // of the thread, nine colour values and the four disparity taps of every
-  // scale each.  Loads are unconditional -- a thread past the end of the region
-  // re-reads pixel 0 and a scale this block does not process re-reads one it
-  // does -- and only the LDS stores are predicated.
+  // of the thread, nine colour values and the depth of every scale each.  Loads
+  // are unconditional -- a thread past the end of the region re-reads pixel 0
+  // and a scale this block does not process re-reads one it does -- and only
+  // the LDS stores are predicated.
   {
     constexpr int NIT = (RH * RW + NT - 1) / NT;
     float col[NIT][9];
-    float tapv[NIT][DW_MAX_SCALES][4];
-    float wy0[NIT][DW_MAX_SCALES], wy1[NIT][DW_MAX_SCALES], wx0[NIT][DW_MAX_SCALES], wx1[NIT][DW_MAX_SCALES];
+    float dep[NIT][DW_MAX_SCALES];
     int lis[NIT];
-    // low-resolution size / full-resolution size of every scale, once (uniform values)
-    float rsy[DW_MAX_SCALES], rsx[DW_MAX_SCALES];
-#pragma unroll
-    for (int s = 0; s < DW_MAX_SCALES; ++s) {
-      const int sc = (s >= s_lo && s < s_hi) ? s : s_lo;
-      rsy[s] = p.rsy[sc];
-      rsx[s] = p.rsx[sc];
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int i = tid + it * NT;
@@ -505,28 +568,12 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         col[it][3 + c] = tap(src_b[0] + c * plane, o);
         col[it][6 + c] = tap(src_b[1] + c * plane, o);
       }
+      // depth of the pixel at every scale (the disparities were up-sampled and inverted once
+      // per pixel by the depth blocks of the launch before this one: a tile copies its region)
 #pragma unroll
       for (int s = 0; s < DW_MAX_SCALES; ++s) {
         const int sc = (s >= s_lo && s < s_hi) ? s : s_lo;
-        const int hs = H >> sc, ws = W >> sc;
-        const GlobalFloats d = uniform_ptr(p.disp[sc] + (long)b * hs * ws);
-        if (sc == 0) {  // uniform: scale 0 is not up-sampled
-          const float v = tap(d, o);
-          tapv[it][s][0] = tapv[it][s][1] = tapv[it][s][2] = tapv[it][s][3] = v;
-          wy0[it][s] = wx0[it][s] = 1.f;
-          wy1[it][s] = wx1[it][s] = 0.f;
-        } else {
-          const Taps ty = upsample_taps(y, hs, rsy[s]);
-          const Taps tx = upsample_taps(x, ws, rsx[s]);
-          tapv[it][s][0] = tap(d, (unsigned)(ty.i0 * ws + tx.i0) * 4u);
-          tapv[it][s][1] = tap(d, (unsigned)(ty.i0 * ws + tx.i1) * 4u);
-          tapv[it][s][2] = tap(d, (unsigned)(ty.i1 * ws + tx.i0) * 4u);
-          tapv[it][s][3] = tap(d, (unsigned)(ty.i1 * ws + tx.i1) * 4u);
-          wy0[it][s] = ty.l0;
-          wy1[it][s] = ty.l1;
-          wx0[it][s] = tx.l0;
-          wx1[it][s] = tx.l1;
-        }
+        dep[it][s] = tap(uniform_ptr(p.depth_up + ((long)sc * p.B + b) * plane), o);
       }
     }
 #pragma unroll
@@ -540,23 +587,9 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
           s_un[(1 * 3 + c) * RN + li] = col[it][6 + c];
         }
       }
-      // depth from the up-sampled disparity of every scale, once per tile: the
-      // per-scale stages then have no dependent global load in front of the taps
 #pragma unroll
-      for (int s = 0; s < DW_MAX_SCALES; ++s) {
-        if (s >= s_lo && s < s_hi && li >= 0) {
-          float du;
-          if (s == 0) {
-            du = tapv[it][s][0];
-          } else {
-            const float top = wx0[it][s] * tapv[it][s][0] + wx1[it][s] * tapv[it][s][1];
-            const float bot = wx0[it][s] * tapv[it][s][2] + wx1[it][s] * tapv[it][s][3];
-            du = wy0[it][s] * top + wy1[it][s] * bot;
-          }
-          const float dsp = kMinDisp + kDispRange * du;
-          s_depth[s * RN + li] = div_by(1.0f, dsp, div_rcp(dsp));  // 1 / dsp
-        }
-      }
+      for (int s = 0; s < DW_MAX_SCALES; ++s)
+        if (s >= s_lo && s < s_hi && li >= 0) s_depth[s * RN + li] = dep[it][s];
     }
   }
   __syncthreads();
@@ -1255,6 +1288,15 @@ __device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, in
 // what the mean is made of, so no pass over disp precedes this kernel.
 template <bool GRAD>
 __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
+  static_assert(SM_NT == DU_NT, "the depth blocks run in this kernel's launch");
+  if ((int)blockIdx.x >= p.L.blk_off[p.S]) {  // the blocks behind the smoothness blocks: depth maps
+    const int k = (int)blockIdx.x - p.L.blk_off[p.S];
+    if (p.du_px == 4)
+      depth_up_block<4>(p, k / p.du_nblk, k % p.du_nblk);
+    else
+      depth_up_block<1>(p, k / p.du_nblk, k % p.du_nblk);
+    return;
+  }
   int s, b, chunk;
   decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
   const int hs = p.L.Hs[s], ws = p.L.Ws[s];
@@ -1874,7 +1916,7 @@ __global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, 
 
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t tile_loss, tile_dP, gdup, img_scal, sm_G, sm_part, total;
+  size_t tile_loss, tile_dP, depth_up, gdup, img_scal, sm_G, sm_part, total;
   // only with DW_FLAG_COLOR_GRAD: [color_zero_begin, color_zero_end) is cleared by every forward call
   size_t gxout, slots, anchors, spill_flag, gcol, color_zero_begin, color_zero_end;
   int cX, cY;  // tiles of the colour scatter
@@ -1918,6 +1960,8 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   o = align_up(o + sizeof(float) * (size_t)L.pix_off[d.S], A);
   w.img_scal = o;
   o = align_up(o + sizeof(float) * (size_t)DW_MAX_SCALES * d.B * 2, A);
+  w.depth_up = o;
+  o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
   w.gdup = o;  // last section (the diagnostic stamps overwrite its start)
   o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
   w.cX = (d.W + CS_TW - 1) / CS_TW;
@@ -2037,6 +2081,7 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.tile_loss = (float*)(ws + w.tile_loss);
   p.tile_dP = (float*)(ws + w.tile_dP);
   p.gdup = (float*)(ws + w.gdup);
+  p.depth_up = (float*)(ws + w.depth_up);
   p.img_scal = (float*)(ws + w.img_scal);
   p.sm_G = (float*)(ws + w.sm_G);
   p.sm_part = (float*)(ws + w.sm_part);
@@ -2062,6 +2107,11 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   const int n_tiles = p.tilesX * p.tilesY * p.B;
   p.n_full = full_blocks(n_tiles, p.S, desc->flags, with_grad ? Geom<true>::PER_CU : Geom<false>::PER_CU);
   const dim3 tgrid(p.n_full + (n_tiles - p.n_full) * p.S);
+  // depth maps: four pixels per thread when rows are whole 16-byte groups (every plane of the
+  // workspace section is 256-byte aligned then)
+  p.du_px = (p.W & 3) ? 1 : 4;
+  p.du_nblk = (p.H * p.W / p.du_px + DU_NT - 1) / DU_NT;
+  const unsigned map_blocks = (unsigned)(p.L.blk_off[p.S] + p.B * p.du_nblk);
   if (desc->flags & DW_FLAG_TILE_KERNEL_ONLY) {
     if (cgrad)
       photo_tile_color_kernel<<<tgrid, Geom<true>::NT, 0, st>>>(p);
@@ -2071,17 +2121,18 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
       photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
     return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
   }
+  // smoothness sums and the depth maps first (one launch), then the tiles, which read the maps
   if (with_grad) {
+    smooth_kernel<true><<<map_blocks, SM_NT, 0, st>>>(p);
     if (cgrad) {
       photo_tile_color_kernel<<<tgrid, Geom<true>::NT, 0, st>>>(p);
       color_scatter_kernel<<<2 * p.B * w.cX * w.cY, CS_NT, 0, st>>>(cp);
     } else {
       photo_tile_kernel<true><<<tgrid, Geom<true>::NT, 0, st>>>(p);
     }
-    smooth_kernel<true><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   } else {
+    smooth_kernel<false><<<map_blocks, SM_NT, 0, st>>>(p);
     photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
-    smooth_kernel<false><<<p.L.blk_off[p.S], SM_NT, 0, st>>>(p);
   }
   // without gradients nobody reads the per-image scalars: block 0 alone
   loss_finalize_kernel<<<with_grad ? 1 + (p.S * p.B + LF_WAVES - 1) / LF_WAVES : 1, 1024, 0, st>>>(p, loss_out);

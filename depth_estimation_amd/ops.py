@@ -225,6 +225,16 @@ class PhotometricPlan:
                    None if tie_noise is None else tie_noise.data_ptr())
         return self
 
+    def tile_kernel_only(self, enable: bool = True):
+        """Profiling: later forward calls launch only the dominant (per-tile) kernel.  Call after
+        one complete forward pass on the bound inputs: the tile kernel reads the depth maps that
+        pass has left in the workspace."""
+        if enable:
+            self.desc.flags |= _lib.DW_FLAG_TILE_KERNEL_ONLY
+        else:
+            self.desc.flags &= ~_lib.DW_FLAG_TILE_KERNEL_ONLY
+        return self
+
     def forward(self, with_grad: bool = True, stream: Optional[int] = None):
         d, c, py, K, iK, T, tie = self._p
         # the host side sizes its launch from the current device, and the stream belongs to it

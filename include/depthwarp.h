@@ -65,7 +65,9 @@ typedef struct dw_desc {
 
 /* Profiling only: dw_photometric_fwd launches just its dominant kernel (the
  * per-tile warp/error/adjoint kernel); outputs other than the masks are then
- * not produced. Used to time that kernel alone with events. */
+ * not produced. Used to time that kernel alone with events.  The kernel reads
+ * the depth maps a complete call leaves in the workspace: make one complete
+ * call with the same inputs and workspace first. */
 #define DW_FLAG_TILE_KERNEL_ONLY 1
 /* Testing only: never split the last tiles of the launch into per-scale blocks
  * (the split is a scheduling choice; results are identical with and without). */

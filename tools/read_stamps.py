@@ -3,7 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from depth_estimation_amd.ops import PhotometricPlan
 from depth_estimation_amd.synth import make_sequence
 seq = make_sequence(12, 192, 640, seed=0).to("cuda")
-plan = PhotometricPlan(12, 192, 640, 4, "cuda", flags=1).bind(*seq.args())
+plan = PhotometricPlan(12, 192, 640, 4, "cuda").bind(*seq.args())
+plan.forward(True)
+plan.tile_kernel_only()
 for _ in range(3): plan.forward(True)
 torch.cuda.synchronize()
 # gd0 is the last workspace section: B*H*W floats

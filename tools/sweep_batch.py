@@ -13,7 +13,9 @@ from depth_estimation_amd.synth import make_sequence  # noqa: E402
 H, W = 192, 640
 for B in [int(a) for a in sys.argv[1:]] or [8, 10, 12, 13, 16, 20, 24, 48]:
     seq = make_sequence(B, H, W, seed=0).to("cuda")
-    plan = PhotometricPlan(B, H, W, 4, "cuda", flags=1).bind(*seq.args())
+    plan = PhotometricPlan(B, H, W, 4, "cuda").bind(*seq.args())
+    plan.forward(True)
+    plan.tile_kernel_only()
     for _ in range(5):
         plan.forward(with_grad=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
