@@ -367,6 +367,13 @@ def test_parity_fewer_scales(S):
     _check_against_oracle(make_sequence(2, 32, 96, S=S, seed=40 + S))
 
 
+@pytest.mark.parametrize("B,H,W,S", [(2, 18, 26, 2), (1, 22, 38, 2), (1, 17, 21, 1)])
+def test_parity_widths_that_are_not_multiples_of_four(B, H, W, S):
+    """Rows that are not whole 16-byte groups: the depth maps and the smoothness sums take their
+    one-pixel-per-thread paths."""
+    _check_against_oracle(make_sequence(B, H, W, S=S, seed=H + W))
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 16, 16), (1, 40, 104), (2, 56, 72), (1, 8, 248)])
 def test_parity_sizes_off_the_tile_grid(B, H, W):
     """Images smaller than one tile, not a multiple of the 14 x 30 tile step, and a single tile row."""
