@@ -330,7 +330,12 @@ __global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, int tiles
   constexpr int RWd = SS_TW + 4, RHt = SS_TH + 4;  // colours: halo 2
   constexpr int QWd = SS_TW + 2, QHt = SS_TH + 2;  // coefficients: halo 1
   __shared__ float sx[RWd * RHt], sy[RWd * RHt];
-  __shared__ float sG[5][QWd * QHt];  // d/d mu_x, E[xx], E[xy], mu_y, E[yy]
+  // Per window: the adjoint with respect to a pixel (x, y) inside it is linear,
+  //   d/dx = c0 + 2 g1 (x - mux) + g2 (y - muy),   d/dy = c3 + 2 g1 (y - muy) + g2 (x - mux),
+  // written around the window's own means: the un-centred form (constant + 2 g1 x + g2 y) sums
+  // terms of the order of the squared means to a result of the order of the variances, which
+  // in float32 loses B1 / B2 of the precision in flat regions.
+  __shared__ float sG[6][QWd * QHt];  // c0, g1, g2, c3, mux, muy
   const long plane = (long)H * W;
   const int tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
   const int y00 = tY * SS_TH - 2, x00 = tX * SS_TW - 2;
@@ -343,28 +348,31 @@ __global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, int tiles
   for (int q = threadIdx.x; q < QWd * QHt; q += SS_NT) {
     const int qy = q / QWd, qx = q - qy * QWd;
     const int yy = y00 + 1 + qy, xx = x00 + 1 + qx;
-    float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
       SsimPx t;
       ssim_px(sx, sy, (qy + 1) * RWd + qx + 1, RWd, t);
       if (t.raw >= 0.f && t.raw <= 1.f) {
         const float up = -0.5f * gp[(long)yy * W + xx] / (t.B1 * t.B2);
-        g[0] = up * (2.0f * t.muy * (t.A2 - t.A1) - t.r * 2.0f * t.mux * (t.B2 - t.B1));
+        g[0] = up * (2.0f * (t.muy * t.A2 - (t.r * t.mux) * t.B2));
         g[1] = up * (-t.r * t.B1);
         g[2] = up * (2.0f * t.A1);
-        g[3] = up * (2.0f * t.mux * (t.A2 - t.A1) - t.r * 2.0f * t.muy * (t.B2 - t.B1));
-        g[4] = g[1];
+        g[3] = up * (2.0f * (t.mux * t.A2 - (t.r * t.muy) * t.B2));
+        g[4] = t.mux;
+        g[5] = t.muy;
       }
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sG[k][q] = g[k];
+    for (int k = 0; k < 6; ++k) sG[k][q] = g[k];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < SS_TH * SS_TW; i += SS_NT) {
     const int cy = i / SS_TW, cx = i - cy * SS_TW;
     const int yy = y00 + 2 + cy, xx = x00 + 2 + cx;
     if (yy >= H || xx >= W) continue;
-    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int pos = (cy + 2) * RWd + cx + 2;
+    const float xv = sx[pos], yv = sy[pos];
+    float ax = 0.f, ay = 0.f;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
       const float wy = 1.f + ((dy == -1 && yy == 1) ? 1.f : 0.f) + ((dy == 1 && yy == H - 2) ? 1.f : 0.f);
@@ -373,15 +381,15 @@ __global__ __launch_bounds__(SS_NT) void ssim_bwd_kernel(int H, int W, int tiles
         const float w = wy * (1.f + ((dx == -1 && xx == 1) ? 1.f : 0.f) +
                               ((dx == 1 && xx == W - 2) ? 1.f : 0.f));
         const int q = (cy + 1 + dy) * QWd + (cx + 1 + dx);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) acc[k] = fmaf(w, sG[k][q], acc[k]);
+        const float dxm = xv - sG[4][q], dym = yv - sG[5][q];  // a window without a gradient has all six planes zero
+        const float g1 = 2.0f * sG[1][q], g2 = sG[2][q];
+        ax = fmaf(w, fmaf(g1, dxm, fmaf(g2, dym, sG[0][q])), ax);
+        ay = fmaf(w, fmaf(g1, dym, fmaf(g2, dxm, sG[3][q])), ay);
       }
     }
-    const int pos = (cy + 2) * RWd + cx + 2;
-    const float xv = sx[pos], yv = sy[pos];
     const long o = blockIdx.y * plane + (long)yy * W + xx;
-    if (g_x) g_x[o] = kNinth * (acc[0] + 2.0f * xv * acc[1] + yv * acc[2]);
-    if (g_y) g_y[o] = kNinth * (acc[3] + 2.0f * yv * acc[4] + xv * acc[2]);
+    if (g_x) g_x[o] = kNinth * ax;
+    if (g_y) g_y[o] = kNinth * ay;
   }
 }
 

@@ -71,6 +71,17 @@ def grad_disp_err(hip, ref, disp):
     return _rel(hip, ref, (~ties).to(ref.dtype))
 
 
+def grad_disp_within_float32_noise(hip, g32, g64, disp):
+    """Pixel by pixel: the kernel may differ from the float32 oracle by the 1e-4 bar plus twice the
+    distance of that oracle value from the float64 evaluation of the same oracle (all relative to
+    the largest entry), and must be no further from float64 than the float32 oracle plus the bar."""
+    keep = (~smoothness_ties(disp)).double()
+    sc = g64.abs().max()
+    noise = (g32.double() - g64).abs() / sc
+    assert float((((hip.double() - g32.double()).abs() / sc - 2 * noise) * keep).max()) <= GRAD_RTOL
+    assert float((((hip.double() - g64).abs() / sc - noise) * keep).max()) <= GRAD_RTOL
+
+
 @pytest.mark.parametrize("B,H,W,tie", [(2, 24, 80, False), (2, 48, 160, False), (1, 64, 192, True),
                                         (3, 32, 64, False)])
 def test_parity_small(B, H, W, tie):
@@ -105,8 +116,23 @@ def test_parity_full_resolution():
 
 
 def test_parity_high_resolution_forward_and_backward():
-    """One sample at 384x1280 (the high-resolution configuration), forward and backward against the oracle."""
-    _check_against_oracle(make_sequence(1, 384, 1280, seed=13))
+    """One sample at 384x1280 (the high-resolution configuration), forward and backward against the
+    oracle.  Among half a million pixels a few have a float32 oracle gradient that is itself
+    2e-4 (of the largest entry) away from the same oracle evaluated in float64, so a second
+    float32 evaluation cannot be expected within 1e-4 of the first everywhere: such pixels are
+    held to the float64 value instead (see `grad_disp_within_float32_noise`)."""
+    seq = make_sequence(1, 384, 1280, seed=13)
+    loss, aux, masks, gd, gT = _oracle(seq)
+    terms, mask, hgd, hgT = _hip(seq)
+    assert torch.equal(mask, masks)
+    assert abs(float(terms[0]) - float(loss)) <= LOSS_RTOL * abs(float(loss))
+    gd64 = None
+    for s in range(4):
+        if grad_disp_err(hgd[s], gd[s], seq.disp[s]) > GRAD_RTOL:
+            if gd64 is None:
+                gd64 = _oracle(seq.to("cpu", torch.float64))[3]
+            grad_disp_within_float32_noise(hgd[s], gd[s], gd64[s], seq.disp[s])
+    assert _rel(hgT[:, :, :3], gT[:, :, :3]) <= GRAD_RTOL
 
 
 def test_batch_of_16_equals_per_sample_calls():
@@ -253,6 +279,30 @@ def test_parity_sweep_outlier_ill_conditioned_pose():
     assert worst_vs_f32 <= 5e-4
     e_hip = _rel(hgT[:, :, :3].double(), gT64[:, :, :3])
     assert e_hip <= 2 * _rel(gT32[:, :, :3].double(), gT64[:, :, :3]) + GRAD_RTOL
+
+
+@pytest.mark.parametrize("seed,B,H,W", [(139, 1, 48, 160), (139, 1, 40, 104), (149, 1, 48, 160), (153, 1, 40, 104)])
+def test_pose_gradient_where_the_warped_image_is_flat(seed, B, H, W):
+    """Translations of tens of metres in a scene a few metres deep: every pixel samples next to
+    the epipole, the warped image is nearly constant and the SSIM adjoint is a difference of
+    terms of the order of the squared means that cancel to the order of the variances.  With the
+    adjoint's constant term formed from un-centred means the kernel was 1.3 - 1.5e-4 from a
+    float64 evaluation in these four cases (the float32 oracle 2 - 5e-5); written around a
+    reference value per tile it is as close as the float32 oracle.  Bars: no further from
+    float64 than 1e-4, nor than the float32 oracle plus 1e-4; masks bit-exact as always."""
+    seq = sweep_case(seed, B, H, W)
+    loss, aux, masks, gd32, gT32 = _oracle(seq)
+    _, _, _, gd64, gT64 = _oracle(seq.to("cpu", torch.float64))
+    terms, mask, hgd, hgT = _hip(seq)
+    assert torch.equal(mask, masks)
+    assert abs(float(terms[0]) - float(loss)) <= LOSS_RTOL * abs(float(loss))
+    e_hip = _rel(hgT[:, :, :3].double(), gT64[:, :, :3])
+    e_f32 = _rel(gT32[:, :, :3].double(), gT64[:, :, :3])
+    assert e_hip <= GRAD_RTOL, (e_hip, e_f32)
+    assert e_hip <= e_f32 + GRAD_RTOL
+    assert _rel(hgT[:, :, :3], gT32[:, :, :3]) <= GRAD_RTOL
+    for s in range(4):
+        assert grad_disp_err(hgd[s], gd32[s], seq.disp[s]) <= GRAD_RTOL
 
 
 def test_upstream_gradient_scales():
