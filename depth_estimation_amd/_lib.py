@@ -48,6 +48,7 @@ _SIGNATURES = {
     "dw_photometric_bwd_color": (C.c_int, [C.POINTER(DwDesc), _VP, _VP, C.c_size_t, _PP, _VP]),
     "dw_compute_loss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "dw_compute_loss_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
+    "dw_compute_loss_pair_fwd": (C.c_int, [C.c_int32] * 4 + [_VP, _VP, _VP, _VP, _VP, C.c_int32, _VP, C.c_size_t, _VP]),
     "dw_compute_loss_fwd_static": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, C.c_int32, _VP]),
     "dw_compute_loss_metrics_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, C.c_float, C.c_float, _VP, C.c_int32,
                                                             _VP, C.c_size_t, _VP]),

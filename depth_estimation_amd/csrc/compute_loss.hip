@@ -45,6 +45,9 @@ struct ClParams {
   int antialias;  // resize with the area-weighted triangle filter instead of two taps per axis
   const void* target;  // float32, or float64 for the kernels instantiated with TT = double
   const float* pred;
+  // pair call: sample 1 lives in buffers of its own (target2, pred2) instead of behind sample 0
+  const void* target2;
+  const float* pred2;
   float* part;  // [B][chunks * strips][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
                 //                                sum (t - clamp(1/p))^2, min p, max p, unused
   float* out;   // [B][4 or 8]
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
   const int chunk = blockIdx.x / p.strips, strip = blockIdx.x - chunk * p.strips;
   const int H = p.H, W = p.W;
   const int x0 = strip * CL_CW, y0 = chunk * p.rows, y1 = min(y0 + p.rows, H);
-  const TT* tg = static_cast<const TT*>(p.target) + (long)b * p.Ht * p.Wt;
-  const float* pr = p.pred + (long)b * H * W;
+  const bool second = p.target2 && b == 1;  // uniform
+  const TT* tg = second ? static_cast<const TT*>(p.target2) : static_cast<const TT*>(p.target) + (long)b * p.Ht * p.Wt;
+  const float* pr = second ? p.pred2 : p.pred + (long)b * H * W;
   const float sy = (float)p.Ht / (float)H, sx = (float)p.Wt / (float)W;
 
   // the lane's columns: its own two, and for the first six lanes one of the halo columns
@@ -393,12 +397,18 @@ done:
 // One block per sample adds the partial sums in double, in a fixed order.  The partials come
 // from other compute units' caches: every thread has its few loads in flight at once (16-byte
 // loads, unrolled), since the kernel is nothing but their latency.
-template <bool METRICS>
-__global__ __launch_bounds__(256) void compute_loss_finalize_kernel(const ClParams p) {
+// PAIR: one block of 512 threads finishes both samples of a pair call, each half exactly as a
+// block of its own would, and then adds the two losses (out[8]).
+template <bool METRICS, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256) void compute_loss_finalize_kernel(const ClParams p) {
   constexpr int PS = METRICS ? 8 : 4, NS = METRICS ? 5 : 4;  // partial stride, number of sums
-  __shared__ double red[NS][256 / kWave];
-  __shared__ float ext[2][256 / kWave];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  __shared__ double red_[PAIR ? 2 : 1][NS][256 / kWave];
+  __shared__ float ext_[PAIR ? 2 : 1][2][256 / kWave];
+  __shared__ float pair_loss[2];
+  const int half = PAIR ? threadIdx.x >> 8 : 0;
+  double (*red)[256 / kWave] = red_[half];
+  float (*ext)[256 / kWave] = ext_[half];
+  const int b = PAIR ? half : blockIdx.x, tid = threadIdx.x & 255, lane = tid & (kWave - 1), wid = tid / kWave;
   const int nt = p.strips * p.chunks;
   double a[NS];
   for (int k = 0; k < NS; ++k) a[k] = 0.0;
@@ -452,6 +462,11 @@ __global__ __launch_bounds__(256) void compute_loss_finalize_kernel(const ClPara
       o[6] = hi;
       o[7] = 0.f;
     }
+    if (PAIR) pair_loss[half] = o[0];
+  }
+  if (PAIR) {
+    __syncthreads();
+    if (threadIdx.x == 0) p.out[2 * PS] = pair_loss[0] + pair_loss[1];
   }
 }
 
@@ -585,11 +600,16 @@ extern "C" size_t dw_compute_loss_workspace_bytes(int32_t B, int32_t H, int32_t 
   return align_up(sizeof(float) * 8 * parts * B, 256);  // enough for the metrics variant too
 }
 
+// target2 / pred2 non-null: a pair call (B must be 2): sample 1 is read from them, the chunk
+// height is that of a one-sample call, and out receives a ninth float, the sum of the two losses.
 template <bool METRICS>
 static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
                                const void* target, const float* pred, float clamp_lo, float clamp_hi,
-                               float* out, int32_t flags, void* workspace, size_t workspace_bytes, void* stream) {
+                               float* out, int32_t flags, void* workspace, size_t workspace_bytes, void* stream,
+                               const void* target2 = nullptr, const float* pred2 = nullptr) {
   if (!target || !pred || !out || !workspace) return DW_ERR_NULL;
+  const bool pair = target2 || pred2;
+  if (pair && (!target2 || !pred2 || B != 2)) return DW_ERR_ARG;
   if (flags & ~(DW_CL_FLAG_ANTIALIAS | DW_CL_FLAG_TARGET_F64)) return DW_ERR_ARG;
   // reflect padding of 3 needs at least 4 pixels per side
   if (B < 1 || B > 65535 || H < 4 || W < 4 || Ht < 1 || Wt < 1) return DW_ERR_SHAPE;
@@ -602,7 +622,7 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   p.Wt = Wt;
   p.H = H;
   p.W = W;
-  p.rows = compute_loss_rows(B, H, W);
+  p.rows = compute_loss_rows(pair ? 1 : B, H, W);
   p.strips = (W + CL_CW - 1) / CL_CW;
   p.chunks = (H + p.rows - 1) / p.rows;
   // one set of partial sums per (strip, chunk) and sample; dw_compute_loss_workspace_bytes is
@@ -612,6 +632,8 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   p.antialias = (flags & DW_CL_FLAG_ANTIALIAS) ? 1 : 0;
   p.target = target;
   p.pred = pred;
+  p.target2 = target2;
+  p.pred2 = pred2;
   p.part = (float*)workspace;
   p.out = out;
   p.clamp_lo = clamp_lo;
@@ -635,7 +657,10 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
     if (mode == 1) compute_loss_strip_kernel<1, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
     if (mode == 2) compute_loss_strip_kernel<2, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
   }
-  compute_loss_finalize_kernel<METRICS><<<B, 256, 0, st>>>(p);
+  if (pair)
+    compute_loss_finalize_kernel<METRICS, true><<<1, 512, 0, st>>>(p);
+  else
+    compute_loss_finalize_kernel<METRICS, false><<<B, 256, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
 
@@ -644,6 +669,15 @@ extern "C" int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   return compute_loss_launch<false>(B, Ht, Wt, H, W, target, pred, 0.f, 0.f, out, flags, workspace,
                                     workspace_bytes, stream);
+}
+
+extern "C" int dw_compute_loss_pair_fwd(int32_t Ht, int32_t Wt, int32_t H, int32_t W, const void* target_l,
+                                        const float* pred_l, const void* target_r, const float* pred_r,
+                                        float* out, int32_t flags, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  if (!target_r || !pred_r) return DW_ERR_NULL;
+  return compute_loss_launch<false>(2, Ht, Wt, H, W, target_l, pred_l, 0.f, 0.f, out, flags, workspace,
+                                    workspace_bytes, stream, target_r, pred_r);
 }
 
 extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,

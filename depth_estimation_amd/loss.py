@@ -18,7 +18,7 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["compute_loss", "compute_loss_terms", "compute_loss_into"]
+__all__ = ["compute_loss", "compute_loss_lr", "compute_loss_terms", "compute_loss_into"]
 
 
 def _as_b1hw(name: str, t: Tensor) -> Tensor:
@@ -30,7 +30,8 @@ def _as_b1hw(name: str, t: Tensor) -> Tensor:
 
 
 # Partial-sum workspaces, one per (device, stream): a call's kernels run on the current
-# stream, so calls that could overlap never share one.  A few KB each; grown on demand.
+# stream, so calls that could overlap never share one.  Sized by the library's upper bound
+# (32 bytes per sample, strip and pair of rows: 16 KB for one 256 x 512 sample, 1 MB at B = 64); grown on demand.
 _workspaces = {}
 
 
@@ -129,6 +130,67 @@ def compute_loss(target: Tensor, pred: Tensor, height: int = None, width: int = 
     (`F.interpolate(..., antialias=True)`)."""
     out = _terms(target, pred, height, width, antialias)
     return out[0, 0] if out.shape[0] == 1 else out[:, 0]
+
+
+def _one_map(name: str, t: Tensor) -> Tensor:
+    """(1,H,W) or (1,1,H,W) -> the tensor itself if it is one contiguous map, else a contiguous copy."""
+    if t.dim() not in (3, 4) or t.numel() != t.shape[-1] * t.shape[-2]:
+        raise RuntimeError(f"{name}: expected one map, (1,H,W) or (1,1,H,W), got {tuple(t.shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def compute_loss_lr(l_target: Tensor, l_pred: Tensor, r_target: Tensor, r_pred: Tensor,
+                    height: int = None, width: int = None, antialias: bool = False,
+                    return_terms: bool = False):
+    """The reference's loss of a training step,
+    `compute_loss(l_depth, l_pred) + compute_loss(r_depth, r_pred)` (train.py:113, 177), as one
+    call: both views go through one launch pair (`dw_compute_loss_pair_fwd`) straight from the four
+    tensors, nothing is stacked or copied, and each view's terms are bit-identical to a
+    `compute_loss` call of its own.  Returns the 0-dim sum; with `return_terms` also the (2, 4)
+    tensor of loss, ssim_term, l1, smooth per view."""
+    with torch.no_grad():
+        lt, lp = _one_map("l_target", l_target), _one_map("l_pred", l_pred)
+        rt, rp = _one_map("r_target", r_target), _one_map("r_pred", r_pred)
+        if not (lt.is_cuda and lp.is_cuda and rt.is_cuda and rp.is_cuda):
+            raise _lib.DepthwarpError("compute_loss_lr: expected ROCm device tensors "
+                                      "(the HIP kernels have no CPU path)")
+        H, W = lp.shape[-2], lp.shape[-1]
+        if tuple(rp.shape[-2:]) != (H, W) or (height is not None and (H, W) != (height, width)):
+            # the reference's `pred.view(1, 1, H, W)` raises on a size mismatch
+            raise RuntimeError(f"predictions have shapes {tuple(lp.shape)} and {tuple(rp.shape)}, expected (1,{height or H},{width or W})")
+        if tuple(rt.shape[-2:]) != tuple(lt.shape[-2:]):
+            raise RuntimeError("compute_loss_lr: the two ground-truth maps differ in size")
+        if lp.dtype != torch.float32:
+            lp = lp.float()
+        if rp.dtype != torch.float32:
+            rp = rp.float()
+        if lt.dtype not in (torch.float32, torch.float64):
+            lt = lt.float()
+        if rt.dtype != lt.dtype:
+            rt = rt.to(lt.dtype)
+        flags = (_lib.DW_CL_FLAG_ANTIALIAS if antialias else 0) | \
+                (_lib.DW_CL_FLAG_TARGET_F64 if lt.dtype == torch.float64 else 0)
+        lib = _lib.lib()
+        nbytes = lib.dw_compute_loss_workspace_bytes(2, H, W)
+        if nbytes == 0:
+            raise _lib.DepthwarpError(f"compute_loss_lr: unsupported shape H={H} W={W}")
+        dev = lp.device
+        out = torch.empty(9, dtype=torch.float32, device=dev)
+        other = torch.cuda.current_device() != dev.index
+        if other:  # the library launches on the current device
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(dev)
+        try:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = _workspace(dev, stream, nbytes)
+            rc = lib.dw_compute_loss_pair_fwd(lt.shape[-2], lt.shape[-1], H, W, lt.data_ptr(), lp.data_ptr(),
+                                              rt.data_ptr(), rp.data_ptr(), out.data_ptr(), flags,
+                                              ws.data_ptr(), ws.numel(), stream)
+        finally:
+            if other:
+                torch.cuda.set_device(prev)
+        _lib.check(rc, "dw_compute_loss_pair_fwd")
+        return (out[8], out[:8].view(2, 4)) if return_terms else out[8]
 
 
 def compute_loss_into(out: Tensor, target: Tensor, pred: Tensor, antialias: bool = False) -> Tensor:

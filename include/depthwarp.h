@@ -188,6 +188,24 @@ DW_API int dw_compute_loss_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
                         const void* target, const float* pred, float* out, int32_t flags,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The reference evaluates its loss twice per step, on the left and on the right
+ * view, and adds the results (train.py:113, 177:
+ * `compute_loss(l_depth, l_pred) + compute_loss(r_depth, r_pred)`).  This entry
+ * point does both in one launch pair without the four maps having to be
+ * stacked into batch tensors: sample 0 is (target_l, pred_l), sample 1
+ * (target_r, pred_r), each a (1,1,Ht,Wt) / (1,1,H,W) map as in
+ * dw_compute_loss_fwd.  The row chunks are those of a one-sample call, so
+ * both sets of terms are bit-identical to two dw_compute_loss_fwd calls with
+ * B = 1.
+ *   out      9 floats: loss, ssim_term, l1, smooth of the left view; the same
+ *            of the right view; out[8] = out[0] + out[4], the reference's sum
+ *   workspace: dw_compute_loss_workspace_bytes(2,H,W) bytes */
+DW_API int dw_compute_loss_pair_fwd(int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                             const void* target_l, const float* pred_l,
+                             const void* target_r, const float* pred_r,
+                             float* out, int32_t flags,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw_compute_loss_fwd for callers that cannot allocate or bring a workspace
  * (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc).  No counterpart in the reference; same kernels and results as

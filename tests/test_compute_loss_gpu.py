@@ -131,6 +131,56 @@ def test_float64_target_is_read_in_place_and_equals_the_cast(B, Ht, Wt, H, W):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("Ht,Wt,H,W,f64,aa", [(375, 1242, 256, 512, True, False), (375, 1242, 256, 512, False, True),
+                                               (192, 640, 192, 640, False, False), (50, 70, 37, 45, True, True)])
+def test_left_right_pair_is_one_call_and_equals_two(Ht, Wt, H, W, f64, aa):
+    """`compute_loss(l_depth, l_pred) + compute_loss(r_depth, r_pred)` (train.py:113, 177) through
+    compute_loss_lr: one launch pair on the four tensors as they are.  Each view's terms are
+    bit-identical to a call of its own (the row chunks are those of a one-sample call) and the
+    sum is the float32 sum of the two losses; also against the CPU restatement."""
+    from oracle.compute_loss import compute_loss as ref
+    from depth_estimation_amd.loss import compute_loss, compute_loss_lr, compute_loss_terms
+    lt, lp = _inputs(1, Ht, Wt, H, W, seed=5)
+    rt, rp = _inputs(1, Ht, Wt, H, W, seed=6)
+    if f64:
+        lt, rt = lt.double(), rt.double()
+    glt, glp, grt, grp = lt.cuda(), lp.cuda(), rt.cuda(), rp.cuda()
+    total, terms = compute_loss_lr(glt, glp, grt, grp, antialias=aa, return_terms=True)
+    assert total.dim() == 0 and not total.requires_grad
+    for i, (t, p) in enumerate(((glt, glp), (grt, grp))):
+        one = compute_loss_terms(t, p, antialias=aa)
+        for j, k in enumerate(("loss", "ssim_term", "l1", "smooth")):
+            assert torch.equal(terms[i, j], one[k][0]), (i, k)
+    two = compute_loss(glt, glp, antialias=aa) + compute_loss(grt, grp, antialias=aa)
+    assert torch.equal(total, two)
+    assert torch.equal(compute_loss_lr(glt, glp, grt, grp, antialias=aa), total)
+    want = ref(lt, lp, antialias=aa) + ref(rt, rp, antialias=aa)
+    assert torch.allclose(total.cpu(), want.float(), rtol=RTOL, atol=0)
+    # (1,1,H,W) maps, as the reference's views produce them, are accepted as they are
+    assert torch.equal(compute_loss_lr(glt[None], glp[None], grt[None], grp[None], antialias=aa), total)
+
+
+def test_left_right_pair_refuses_what_the_reference_refuses():
+    from depth_estimation_amd import _lib
+    from depth_estimation_amd.loss import compute_loss_lr
+    a, b = torch.rand(1, 32, 32).cuda(), torch.rand(1, 32, 32).cuda()
+    with pytest.raises(RuntimeError):
+        compute_loss_lr(a, b, a, b, 64, 64)                       # not the configured size
+    with pytest.raises(RuntimeError):
+        compute_loss_lr(a, b, a, torch.rand(1, 16, 32).cuda())    # views of different sizes
+    with pytest.raises(RuntimeError):
+        compute_loss_lr(torch.rand(2, 32, 32).cuda(), b, a, b)    # a batch is not one map
+    with pytest.raises(_lib.DepthwarpError):
+        compute_loss_lr(a.cpu(), b.cpu(), a.cpu(), b.cpu())
+    # the C entry point: a pair needs both buffers of the second view
+    lib = _lib.lib()
+    n = lib.dw_compute_loss_workspace_bytes(2, 32, 32)
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = torch.empty(9, device="cuda")
+    assert lib.dw_compute_loss_pair_fwd(32, 32, 32, 32, a.data_ptr(), b.data_ptr(), None, b.data_ptr(), out.data_ptr(),
+                                        0, ws.data_ptr(), n, None) == -1  # DW_ERR_NULL
+
+
 def test_shape_mismatch_raises():
     from depth_estimation_amd.loss import compute_loss
     with pytest.raises(RuntimeError):

@@ -1,15 +1,32 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
-from depth_estimation_amd.loss import compute_loss
+"""Host time per call of the reference's loss through the Python entry points (GPU box):
+one view per call (compute_loss, as train.py:113 makes two of per step) and both views in one
+call (compute_loss_lr)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from depth_estimation_amd.loss import compute_loss, compute_loss_lr
 t64 = torch.rand(1, 375, 1242, dtype=torch.float64, device="cuda")
-t32 = t64.float()
+r64 = torch.rand(1, 375, 1242, dtype=torch.float64, device="cuda")
 pred = torch.rand(1, 256, 512, device="cuda")
-for name, t in (("f64 target", t64), ("f32 target", t32)):
-    for _ in range(50): compute_loss(t, pred)
+pred_r = torch.rand(1, 256, 512, device="cuda")
+
+
+def clock(fn, n=300):
+    for _ in range(50):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(300): compute_loss(t, pred)
+    for _ in range(n):
+        fn()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(name, "enqueue %.1f us/call, until drained %.1f us/call" % (1e6 * (t1 - t0) / 300, 1e6 * (t2 - t0) / 300))
+    return 1e6 * (t1 - t0) / n, 1e6 * (t2 - t0) / n
+
+
+for name, t, r in (("f64 target", t64, r64), ("f32 target", t64.float(), r64.float())):
+    e, d = clock(lambda: compute_loss(t, pred))
+    print(name, "one view per call: enqueue %.1f us/call, until drained %.1f us/call" % (e, d))
+    e, d = clock(lambda: compute_loss(t, pred) + compute_loss(r, pred_r))
+    print(name, "two calls and an add (a step of the reference): enqueue %.1f us/pair, until drained %.1f us/pair" % (e, d))
+    e, d = clock(lambda: compute_loss_lr(t, pred, r, pred_r))
+    print(name, "compute_loss_lr: enqueue %.1f us/pair, until drained %.1f us/pair" % (e, d))
