@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--amp", action="store_true",
                     help="train mode: run the networks under bfloat16 autocast (the loss op stays float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="op mode at one GPU: skip the secondary workloads that follow the headline measurement")
     ap.add_argument("--cpu-batch", type=int, default=4, help="sequences in the CPU baseline sample")
     args = ap.parse_args(argv)
     if args.batch is None:
@@ -145,30 +147,36 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def roofline(args, seq, dev, alg_total):
-    """Times the dominant kernel alone (HIP events on its stream) and prices it against the HBM
-    peak by its algorithmic bytes; the vector-issue limit, which is what binds this kernel, is
-    reported beside it from the counters of the last profiler pass over the same sources."""
+def tile_kernel_ms(B, H, W, S, seq, dev, reps):
+    """Average duration of the dominant kernel alone: HIP events on the stream it is launched on."""
     from depth_estimation_amd.ops import PhotometricPlan
-    B, H, W, S = args.batch, args.height, args.width, 4
     tile_plan = PhotometricPlan(B, H, W, S, dev).bind(*seq.args())
     tile_plan.forward(with_grad=True)   # a complete pass leaves the depth maps the tile kernel reads
     tile_plan.tile_kernel_only()
     for _ in range(10):
         tile_plan.forward(with_grad=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(20, min(args.steps, 200))
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
         tile_plan.forward(with_grad=True)
     e1.record()
     torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / reps
+
+
+def roofline(args, seq, dev, alg_total):
+    """Times the dominant kernel alone (HIP events on its stream) and prices it against the HBM
+    peak by its algorithmic bytes -- the roofline this benchmark is specified against.  What binds
+    the kernel is the vector pipes: that limit is reported beside it (`limits`, `binding`) from the
+    counters of the last profiler pass over the same sources."""
+    B, H, W, S = args.batch, args.height, args.width, 4
+    k_ms = tile_kernel_ms(B, H, W, S, seq, dev, max(20, min(args.steps, 200)))
     achieved = alg_total / (k_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "kernel": "photo_tile_kernel<true>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": k_ms,
-           "algorithmic_bytes": alg_total}
+           "algorithmic_bytes": alg_total,
+           "note": "priced against HBM as specified; the kernel is bound by the vector pipes, see limits / binding"}
     # Counters cannot be collected from inside the run (the profiler wraps the process): they come
     # from the committed summary of the last rocprofv3 --pmc passes, and only if that summary was
     # measured on the sources this library was built from and on this workload.
@@ -193,7 +201,12 @@ def roofline(args, seq, dev, alg_total):
                 limits.append({"bound": "valu_pipe", "achieved": pipe_ms, "peak": k_ms, "unit": "ms of vector-pipe "
                                "time per launch (achieved) within the launch's duration (peak)",
                                "frac": pipe_ms / k_ms, "wave_instructions_per_launch": insts,
-                               "pipe_cycles_per_instruction": per})
+                               "pipe_cycles_per_instruction": per,
+                               # the same from the counter alone, without the per-opcode cost model:
+                               # the fraction if every instruction held its pipe for two cycles, and
+                               # the SIMD cycles the launch actually spent per vector instruction
+                               "valu_ideal": insts * 2.0 / (SIMD_CYCLES_PER_S * k_ms * 1e-3),
+                               "cycles_per_valu_inst": SIMD_CYCLES_PER_S * k_ms * 1e-3 / insts})
         elif entry is not None:
             out["traffic_stale"] = True  # counters of an older build: not reported
     out["limits"] = limits
@@ -213,8 +226,8 @@ def run_op(args, ctx):
     dp = args.mode == "dp"
     bucket = None
     if dp:
-        # what a data-parallel trainer exchanges per step: the networks' flat gradient bucket and
-        # the scalar loss in its last slot (depth_estimation_amd/train.py::FlatGradBucket)
+        # what a data-parallel trainer exchanges per step: the networks' flat gradient bucket with
+        # the scalar loss in slot 0 (depth_estimation_amd/train.py::FlatGradBucket)
         bucket = torch.zeros(DP_BUCKET_FLOATS + 1, dtype=torch.float32, device="cpu" if ctx["rehearsal"] else dev)
 
     def op_step():
@@ -222,13 +235,22 @@ def run_op(args, ctx):
         plan.backward()
 
     def dp_step():
-        op_step()
-        if ctx["rehearsal"]:
-            bucket[-1] = float(plan.loss[0])
-        else:
-            bucket[-1:].copy_(plan.loss[:1])
+        # As in the trainer, whose gradient hooks start a chunk's all-reduce while backward is still
+        # running: the bucket's exchange (the gradients of the networks; here a stand-in of the same
+        # size) is started asynchronously before this rank's backward pass is enqueued and waited
+        # for after it, the loss (slot 0) follows in an exchange of its own.
+        plan.forward(with_grad=True)
+        handle = None
         if dist is not None:
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            handle = dist.all_reduce(bucket[1:], op=dist.ReduceOp.SUM, async_op=True)
+        plan.backward()
+        if ctx["rehearsal"]:
+            bucket[0] = float(plan.loss[0])
+        else:
+            bucket[:1].copy_(plan.loss[:1])
+        if dist is not None:
+            dist.all_reduce(bucket[:1], op=dist.ReduceOp.SUM)
+            handle.wait()
         bucket.mul_(1.0 / world)
 
     step = dp_step if dp else op_step
@@ -283,7 +305,8 @@ def run_op(args, ctx):
         "config": {"workload": f"{what}, {H}x{W}, batch={B}/GPU, 2 source frames, 4 scales",
                    "mode": args.mode, "global_batch": B * world,
                    "launch": "eager" if graph is None else "hip-graph",
-                   "collective": ("all-reduce (sum) of %d floats per step, %s" %
+                   "collective": ("all-reduce (sum) of %d floats per step, started before this rank's backward "
+                                  "pass is enqueued and waited for after it, %s" %
                                   (DP_BUCKET_FLOATS + 1, "gloo rehearsal" if ctx["rehearsal"] else "RCCL")) if dp
                    else "none: the stack shards by batch and exchanges nothing"},
         "hbm_gbps_algorithmic": world * alg["total"] / per_step / 1e9,
@@ -299,11 +322,117 @@ def run_op(args, ctx):
             dist.all_reduce(bucket)
         torch.cuda.synchronize()
         out["allreduce_ms"] = 1e3 * (time.perf_counter() - t) / 20
+        # the same step without the exchange: what of the all-reduce the step did not hide
+        for _ in range(5):
+            op_step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(50):
+            op_step()
+        torch.cuda.synchronize()
+        out["op_only_ms"] = 1e3 * (time.perf_counter() - t) / 50
+        out["exposed_allreduce_ms"] = max(0.0, 1e3 * per_step - out["op_only_ms"])
     if rank == 0:
         out["roofline"] = roofline(args, seq, dev, alg["total"])
+        if world == 1 and not dp and not args.no_secondary and (B, H, W) == (12, 192, 640):
+            out["secondary"] = secondary_workloads(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     return out
+
+
+def secondary_workloads(dev, steps=60):
+    """The other single-GPU workloads of the benchmark's configurations, timed after the headline
+    one in the same run (each `steps` steps after 10 of warm-up, HIP events; eager launches):
+    the high-resolution shard (8 x 384x1280), the data-parallel shard (16 x 192x640, with the
+    bucket and loss bookkeeping of a data-parallel step but no exchange: one rank), and the
+    reference's own loss function at its own sizes -- one view per call and both views in one."""
+    from depth_estimation_amd.synth import make_sequence, algorithmic_bytes
+    from depth_estimation_amd.ops import PhotometricPlan
+    from depth_estimation_amd.loss import compute_loss, compute_loss_lr
+    from depth_estimation_amd._lib import lib
+
+    def events(fn, n, warm=10):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    res = []
+    for name, B, H, W, bucketed in (("high-resolution shard", 8, 384, 1280, False),
+                                    ("data-parallel shard at one rank", 16, 192, 640, True)):
+        seq = make_sequence(B, H, W, S=4, seed=0).to(dev)
+        plan = PhotometricPlan(B, H, W, 4, dev).bind(*seq.args())
+        bucket = torch.zeros(DP_BUCKET_FLOATS + 1, dtype=torch.float32, device=dev) if bucketed else None
+
+        def step():
+            plan.forward(with_grad=True)
+            plan.backward()
+            if bucket is not None:
+                bucket[:1].copy_(plan.loss[:1])
+                bucket.mul_(1.0)
+
+        ms = events(step, steps)
+        alg = algorithmic_bytes(B, H, W, 4)["total"]
+        k_ms = tile_kernel_ms(B, H, W, 4, seq, dev, steps)
+        res.append({"workload": f"{name}: warp+SSIM/L1+smoothness fwd/bwd, {H}x{W}, batch={B}, 2 source frames, "
+                                "4 scales" + (", + bucket bookkeeping of %d floats" % (DP_BUCKET_FLOATS + 1) if bucketed else ""),
+                    "ms_per_step": ms, "frames_per_s": 3 * B / (ms * 1e-3),
+                    "roofline": {"bound": "hbm", "kernel": "photo_tile_kernel<true>", "kernel_ms": k_ms,
+                                 "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg}})
+        del plan, seq, bucket
+    # Train.compute_loss at the reference's sizes (/root/reference/train.py:272-309, config.py:20-21):
+    # float64 375x1242 ground truth, 256x512 prediction; train.py:113 evaluates it on two views
+    Ht, Wt, H, W = 375, 1242, 256, 512
+    g = torch.Generator().manual_seed(0)
+    lt, rt = (torch.rand(1, Ht, Wt, generator=g, dtype=torch.float64).to(dev) for _ in range(2))
+    lp, rp = (torch.rand(1, H, W, generator=g).to(dev) for _ in range(2))
+    L = lib()
+    nb = L.dw_compute_loss_workspace_bytes(2, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out9 = torch.empty(9, device=dev)
+    F64 = 2  # DW_CL_FLAG_TARGET_F64
+
+    def raw_one():
+        assert L.dw_compute_loss_fwd(1, Ht, Wt, H, W, lt.data_ptr(), lp.data_ptr(), out9.data_ptr(), F64,
+                                     ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream) == 0
+
+    def raw_pair():
+        assert L.dw_compute_loss_pair_fwd(Ht, Wt, H, W, lt.data_ptr(), lp.data_ptr(), rt.data_ptr(), rp.data_ptr(),
+                                          out9.data_ptr(), F64, ws.data_ptr(), nb,
+                                          torch.cuda.current_stream().cuda_stream) == 0
+
+    def wall(fn, n):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    for name, views, call, raw in (("one view per call", 1, lambda: compute_loss(lt, lp), raw_one),
+                                   ("both views of a step in one call (compute_loss_lr)", 2,
+                                    lambda: compute_loss_lr(lt, lp, rt, rp), raw_pair)):
+        raw()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            raw()
+        k_ms = events(graph.replay, steps)   # the two launches of a call without the host between them
+        ms = wall(call, max(steps, 200))     # the Python call as the reference would make it, host included
+        nbytes = views * (8 * Ht * Wt + 4 * H * W)
+        res.append({"workload": f"Train.compute_loss, {name}: float64 ({Ht},{Wt}) ground truth against ({H},{W}) predictions",
+                    "ms_per_step": ms, "frames_per_s": views / (ms * 1e-3),
+                    "roofline": {"bound": "hbm", "kernel": "compute_loss_strip_kernel + finalisation", "kernel_ms": k_ms,
+                                 "frac": nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": nbytes}})
+    return res
 
 
 def run_train(args, ctx):

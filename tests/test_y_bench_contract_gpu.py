@@ -3,6 +3,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -11,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
+    t_start = time.time()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
                           "--cpu-batch", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -31,6 +33,18 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # the other single-GPU workloads ride in the same line: the high-resolution shard, the
+    # data-parallel shard, and the reference's own loss function (one view per call; both views in one)
+    sec = d["secondary"]
+    assert len(sec) == 4
+    for e, (what, units) in zip(sec, (("384x1280, batch=8", 24), ("192x640, batch=16", 48), ("one view per call", 1),
+                                       ("both views", 2))):
+        assert what in e["workload"], e["workload"]
+        assert e["ms_per_step"] > 0 and abs(e["frames_per_s"] - units / (e["ms_per_step"] * 1e-3)) <= 1e-6 * e["frames_per_s"]
+        r = e["roofline"]
+        assert 0 < r["kernel_ms"] <= e["ms_per_step"] * 1.05 and 0 < r["frac"] < 1
+    # the whole run stays a matter of seconds (the contract: well within minutes)
+    assert time.time() - t_start < 60
 
 
 def _run(args, env=None):
@@ -85,6 +99,7 @@ def _run_launched(args):
 def test_one_rank_under_the_launcher_runs_the_collectives_over_rccl():
     d = _run_launched(["--mode", "dp", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 16 and d["allreduce_ms"] > 0
+    assert d["op_only_ms"] > 0 and 0 <= d["exposed_allreduce_ms"] <= d["ms_per_step"]
     d = _run_launched(["--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 12
     d = _run_launched(["--mode", "train", "--steps", "3", "--warmup", "1", "--net-width", "16"])

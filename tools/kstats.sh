@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 for so in "$@"; do
   n=$(basename $so .so)
-  DEPTHWARP_LIB=$R/$so timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$n -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+  DEPTHWARP_LIB=$R/$so timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ks_$n -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
   echo "== $n"
   f=$(find $R/gpurun_out/ks_$n -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'

@@ -12,7 +12,7 @@ step() { echo "== $1" >&2; }
 step bench
 timeout -k 10 200 python3 $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err || exit 1
 step kernel-stats
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/prof.err || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $O/bench_under_rocprofv3.json 2> $O/prof.err || exit 1
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 step pmc-12x192x640
 bash $R/tools/pmc_tile.sh $O/pmc > $O/pmc.txt 2>&1 || exit 1
@@ -25,11 +25,11 @@ done
 unset DW_B DW_H DW_W
 python3 $R/tools/pmc_summary.py $O/pmc_hi --kernel photo_tile --json $O/tile_pmc_8x384x1280.json > /dev/null
 step sweep
-timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --batch 48 > $O/bench_b48.json 2>> $O/bench.err || exit 1
-timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --batch 96 > $O/bench_b96.json 2>> $O/bench.err || exit 1
-timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --batch 8 --height 384 --width 1280 > $O/bench_384x1280_b8.json 2>> $O/bench.err || exit 1
+timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --batch 48 > $O/bench_b48.json 2>> $O/bench.err || exit 1
+timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --batch 96 > $O/bench_b96.json 2>> $O/bench.err || exit 1
+timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --batch 8 --height 384 --width 1280 > $O/bench_384x1280_b8.json 2>> $O/bench.err || exit 1
 step dp
-timeout -k 10 120 python3 $R/bench.py --mode dp --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_dp_n1.json 2>> $O/bench.err || exit 1
+timeout -k 10 120 python3 $R/bench.py --mode dp --steps 100 --warmup 10 --no-cpu-baseline --no-secondary > $O/bench_dp_n1.json 2>> $O/bench.err || exit 1
 step train
 timeout -k 10 300 python3 $R/bench.py --mode train --steps 30 --warmup 5 > $O/bench_train.json 2>> $O/bench.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --mode train --steps 30 --warmup 5 > $O/bench_train_under_rocprofv3.json 2> $O/prof_train.err || exit 1
