@@ -37,6 +37,8 @@
 // because the adjoint of the window sums at a pixel needs the error terms of
 // its eight neighbours; tiles therefore step by (QH-2) x (QW-2).  Forward-only
 // blocks have core = Q and step by QH x QW.
+#include <atomic>
+
 #include "dw_common.h"
 
 namespace dw {
@@ -1737,12 +1739,11 @@ struct ColorParams {
   unsigned* spill_flag;       // set when any tap went to gcol
 };
 
-// v in 2^-32 units, rounded towards minus infinity: floor(v) in the upper word, the fraction
-// (exact: v - floor(v) has no rounding below 2^24) scaled by 2^32 in the lower one.  |v| < 2^31.
+// v in 2^-32 units as a two's-complement 64-bit integer, truncated towards zero.  The product
+// v * 2^32 is exact (a power of two) and, for |v| < 2^31, inside the range of the conversion;
+// every contribution, whatever its sign, is off by less than one unit (2^-32).
 __device__ __forceinline__ unsigned long long to_fixed(float v) {
-  const float hi = floorf(v);
-  const unsigned lo = (unsigned)((v - hi) * 4294967296.0f);
-  return ((unsigned long long)(unsigned)(int)hi << 32) | lo;
+  return (unsigned long long)(long long)(v * 4294967296.0f);
 }
 
 __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorParams p) {
@@ -2018,16 +2019,18 @@ static int check_desc(const dw_desc* d) {
 }
 
 // Resident-block capacity of the current device for a tile kernel compiled for `per_cu` blocks per CU.
+// (The compute-unit count of a device is looked up once and kept: relaxed atomics, since
+// concurrent first calls all store the same value.)
 static int tile_slots(int per_cu) {
-  static int cached[64] = {0};
+  static std::atomic<int> cached[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  if (cached[dev] == 0) {
-    int cus = 0;
+  int cus = cached[dev].load(std::memory_order_relaxed);
+  if (cus == 0) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    cached[dev] = cus;
+    cached[dev].store(cus, std::memory_order_relaxed);
   }
-  return cached[dev] * per_cu;
+  return cus * per_cu;
 }
 
 // All tiles take the same time, so a launch runs in rounds of `slots` blocks

@@ -82,7 +82,9 @@ class FlatGradBucket:
     a hook on every parameter counts its chunk down and, when the chunk's last gradient has been
     accumulated, starts that chunk's all-reduce at once (asynchronously, RCCL's own stream), so
     the exchange of the late layers runs while backward is still working on the early ones.
-    `finish()` waits for the chunks and turns the sums into means."""
+    `finish()` waits for the chunks and turns the sums into means.  The hooks act only between
+    `begin()` and `finish()`; a backward pass outside that bracket leaves the exchange to the
+    caller (`all_reduce_mean`: the whole buffer at once, blocking)."""
 
     def __init__(self, params, n_chunks: int = 4):
         self.params = [p for p in params if p.requires_grad]
@@ -111,6 +113,7 @@ class FlatGradBucket:
         self._size = [self._chunk_of.count(c) for c in range(len(first))]
         self._left = list(self._size)
         self._handles = []
+        self._armed = False  # set by begin(), cleared by finish(): only then do the hooks start exchanges
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda _p, c=self._chunk_of[i]: self._grad_ready(c))
 
@@ -122,6 +125,7 @@ class FlatGradBucket:
         """Call before backward: clears the counters and stores the loss in its slot."""
         self._left = list(self._size)
         self._handles = []
+        self._armed = True
         self.flat[0] = loss.detach()
 
     @staticmethod
@@ -131,6 +135,8 @@ class FlatGradBucket:
         return dist.is_available() and dist.is_initialized()
 
     def _grad_ready(self, c: int):
+        if not self._armed:
+            return
         self._left[c] -= 1
         if self._left[c] == 0 and self._exchanging():
             lo, hi = self._ranges[c]
@@ -142,6 +148,10 @@ class FlatGradBucket:
     def finish(self) -> torch.Tensor:
         """Call after backward: waits for the chunk all-reduces, averages; returns the mean loss."""
         world = self._world()
+        if not self._armed:
+            raise RuntimeError("FlatGradBucket.finish() without begin(): no exchange was started "
+                               "(use all_reduce_mean for a blocking exchange after a plain backward)")
+        self._armed = False
         if self._exchanging():
             if any(n != 0 for n in self._left):  # a parameter got no gradient this step: its chunk never fired
                 for h in self._handles:
@@ -150,11 +160,18 @@ class FlatGradBucket:
                                  for c, (lo, hi) in enumerate(self._ranges) if self._left[c] != 0]
             for h in self._handles:
                 h.wait()
+            self._handles = []
             self.flat.mul_(1.0 / world)
         return self.flat[0]
 
     def all_reduce_mean(self, loss: torch.Tensor) -> torch.Tensor:
-        """One blocking exchange of the whole buffer (no overlap with backward)."""
+        """One blocking exchange of the whole buffer after a backward pass that was not bracketed by
+        begin() / finish() (no overlap with backward).  Refused between begin() and finish(): the
+        hooks have then started chunk exchanges of their own, and a second sum over the same
+        memory would count those chunks twice."""
+        if self._armed:
+            raise RuntimeError("FlatGradBucket.all_reduce_mean() between begin() and finish(): "
+                               "the chunk exchanges are already running; call finish()")
         self.flat[0] = loss.detach()
         if self._exchanging():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

@@ -35,6 +35,70 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_blocking(rank, world, port, out):
+    """The same step with the blocking exchange: plain backward (hooks not armed), then one
+    all-reduce of the whole buffer; a second step makes sure nothing carries over."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)
+        seq = shard(make_sequence(B, H, W, seed=1), rank, world)
+        grads = []
+        for _ in range(2):
+            tr.bucket.zero()
+            loss = tr.forward_loss(seq)
+            loss.backward()
+            assert tr.bucket._handles == [] and tr.bucket._left == tr.bucket._size   # no hook acted
+            mean = tr.bucket.all_reduce_mean(loss)
+            grads.append(tr.bucket.flat[1:].numpy().copy())
+        # misuse is refused instead of summing chunks twice
+        tr.bucket.zero()
+        loss = tr.forward_loss(seq)
+        tr.bucket.begin(loss)
+        loss.backward()
+        try:
+            tr.bucket.all_reduce_mean(loss)
+            refused = False
+        except RuntimeError:
+            refused = True
+        tr.bucket.finish()
+        out.put((rank, float(mean), grads[0], grads[1], refused, tr.bucket.flat[1:].numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_blocking_exchange_matches_the_overlapped_one():
+    """FlatGradBucket.all_reduce_mean after a plain backward pass gives the gradients of the
+    hook-driven exchange (world size 2, gloo), step after step; between begin() and finish() it raises."""
+    torch.set_num_threads(4)
+    ref = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)
+    ref.bucket.zero()
+    full = make_sequence(B, H, W, seed=1)
+    loss = ref.forward_loss(full)
+    loss.backward()
+    ref_grad = ref.bucket.flat[1:].clone()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_blocking, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, mean, g_first, g_second, refused, g_hooks in res:
+        g1, g2, g3 = torch.from_numpy(g_first), torch.from_numpy(g_second), torch.from_numpy(g_hooks)
+        assert refused
+        assert torch.equal(g1, g2)          # the second step is not polluted by the first
+        assert torch.equal(g1, g3)          # blocking and hook-driven exchanges agree bit for bit (sum of two ranks)
+        rel = float((g1 - ref_grad).abs().max() / ref_grad.abs().max())
+        assert rel <= 1e-3, rel
+        assert abs(mean - float(loss)) <= 1e-5 * abs(float(loss))
+    assert torch.equal(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2]))
+
+
 def test_two_rank_step_matches_full_batch():
     torch.set_num_threads(4)
     ref = Trainer("cpu", loss_fn=_oracle_loss, width=4, seed=0)

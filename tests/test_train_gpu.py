@@ -58,3 +58,29 @@ def test_plan_loss_matches_the_allocating_op_and_accumulates_on_leaves():
     disp_c, T_c = leaves()
     loss_fn.terms(disp_c, seq.color, seq.color_pyr, seq.K, seq.inv_K, T_c)[2].backward()
     assert float(disp_c[1].grad.abs().max()) > 0 and float(disp_c[0].grad.abs().max()) == 0
+
+
+def test_trainer_main_under_the_launcher_with_one_rank():
+    """`python -m torch.distributed.run --nproc-per-node 1 -m depth_estimation_amd.train`: the trainer's
+    own entry point with a one-rank RCCL process group -- initialisation on the rank's device, the
+    chunked all-reduces started from the gradient hooks, `finish()`, Adam, teardown -- as on a node."""
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "depth_estimation_amd.train", "--steps", "3", "--batch", "2",
+           "--height", "64", "--width", "128"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    m = re.search(r"loss ([0-9.]+)\s+([0-9.]+) ms/step\s+([0-9]+) frames/s on 1 GPU", out.stdout)
+    assert m, out.stdout
+    assert 0.0 < float(m.group(1)) < 1.0

@@ -9,8 +9,6 @@ O=$R/gpurun_out/$T
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 step() { echo "== $1" >&2; }
-step bench
-timeout -k 10 200 python3 $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err || exit 1
 step kernel-stats
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary > $O/bench_under_rocprofv3.json 2> $O/prof.err || exit 1
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
@@ -24,6 +22,15 @@ for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
 done
 unset DW_B DW_H DW_W
 python3 $R/tools/pmc_summary.py $O/pmc_hi --kernel photo_tile --json $O/tile_pmc_8x384x1280.json > /dev/null
+# the counters go into the file bench.py reads `roofline.traffic` and the pipe limit from (stamped with the
+# sources' hash; the instruction-cost figure was put there before this run by tools/valu_pipe_model.py --write),
+# and only then is the bench line of the round taken, so that it carries them
+step traffic
+python3 $R/tools/pmc_traffic.py $O/tile_pmc.json 12 192 640 --source profiles/${T}_tile_pmc.json > /dev/null || exit 1
+python3 $R/tools/pmc_traffic.py $O/tile_pmc_8x384x1280.json 8 384 1280 --source profiles/${T}_tile_pmc_8x384x1280.json > /dev/null || exit 1
+cp $R/profiles/traffic_latest.json $O/traffic_latest.json
+step bench
+timeout -k 10 200 python3 $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err || exit 1
 step sweep
 timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --batch 48 > $O/bench_b48.json 2>> $O/bench.err || exit 1
 timeout -k 10 120 python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --batch 96 > $O/bench_b96.json 2>> $O/bench.err || exit 1

@@ -84,7 +84,13 @@ def main():
     print(f"per tile and wave: {insts:.0f} vector instructions, {cycles:.0f} pipe cycles -> {per:.3f} cycles per instruction")
     if "--write" in sys.argv:
         path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        doc = json.load(open(path))
+        sys.path.insert(0, ROOT)
+        from bench import kernel_sources_sha
+        sha = kernel_sources_sha()
+        doc = json.load(open(path)) if os.path.exists(path) else {}
+        if doc.get("sources_sha") != sha:
+            # counters of other sources do not belong beside this figure: tools/pmc_traffic.py refills them
+            doc = {"kernel": "photo_tile_kernel<true>", "sources_sha": sha, "workloads": {}}
         doc["valu_pipe_cycles_per_inst"] = per
         doc["valu_pipe_note"] = ("average vector-pipe cycles per vector instruction of photo_tile_kernel<true>: opcode histogram "
                                  "of its segments weighted with the per-opcode costs measured by tools/micro/valu_rates.hip "
