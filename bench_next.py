@@ -203,7 +203,7 @@ def bench_lidar(args):
     nbytes = B * n * 16 + kept * 24 + B * H * W * 8   # scan in, kept points out, depth map out
     o = line("lidar_project", "scans/s", B, ms, args,
              f"{B} scans x {n} points -> {H}x{W} sparse depth (float64), {kept // B} points kept per scan",
-             "lidar_depth_kernel", nbytes)
+             "lidar_project_kernel", nbytes)
     o["dtype"] = "f64"
     if not args.no_cpu_baseline:
         from oracle.lidar import project_scan

@@ -19,18 +19,30 @@
 //   pixel index: (y, W-1) and (y+1, 0) share a key.  Kept as is.
 //   depth < 0 -> 0                                                  (:148)
 //
-// "Last wins", "first of the group" and "minimum of the group" are computed
-// with integer max / min atomics on the compacted point index and on an
-// order-preserving integer image of z: independent of execution order.  They
-// are kept per pixel, in one 16-byte record (one cache line per point): a group is a
-// pixel, or the two pixels (y, W-1) and (y+1, 0), whose records are combined when the map
-// is written.  The map itself is written sparsely: zero fill, then one thread per kept
-// point decides the pixel it is the last point of.
+// What that amounts to.  Two different pixels share a key only as the pair (y, W-1), (y+1, 0).
+// A pixel of the columns 1 .. W-2 is therefore a group of its own: one point -> its z, several
+// -> their minimum, i.e. the minimum either way, and with :148, max(min z, 0) = min max(z, 0).
+// That is one integer atomic per point straight into the output map: the map is zero-filled, a
+// point stores max(z, 0) with the sign bit set (as a signed 64-bit integer every such pattern is
+// below zero -- the empty pixel -- and ordered like z), atomicMin, and the second pass over the
+// points, which writes the compacted list, clears the sign bit of each kept point's pixel again
+// (idempotent: every point of a pixel may do it).  No per-pixel records, no second dense array.
+// Only the points of the two border columns (2 in W of them) need "last in scan order", "first of
+// the group" and the group minimum: they go through three integer atomics on a small per-row
+// record, and a last kernel with one thread per border pixel writes those pixels.  Every result
+// is independent of the execution order.
 #include "dw_common.h"
 
 namespace dw {
 
 constexpr int LD_NT = 256;
+
+// per scan, border column (0: x = 0, 1: x = W - 1) and row; all-zero = no point
+struct __attribute__((aligned(16))) EdgeRec {
+  long long nz;  // smallest encoded z of the pixel's points (see encode_z)
+  int last1;     // 1 + the largest compacted index landing on the pixel
+  int nfirst;    // 0x7fffffff - the smallest one
+};
 
 struct LidarParams {
   int B, n_max, H, W, vel_depth, nblk;
@@ -41,38 +53,43 @@ struct LidarParams {
   int* n_valid;           // (B) out
   double* depth;          // (B, H, W) out
   // workspace
-  int* loc;               // (B, n_max)  pixel index of point i, -1 if dropped
-  double* zbuf;           // (B, n_max)  z of point i
-  int* blk_count;         // (B, nblk)   kept points per block, then exclusive offsets
-  struct PixRec* rec;     // (B, H*W)
+  // kept points of block k of scan b, in scan order, at [b][k * LD_NT + 0 .. blk_count[b][k])
+  int* loc;               // (B, nblk * LD_NT)  pixel index
+  double* zbuf;           // (B, nblk * LD_NT)  z
+  int* blk_count;         // (B, nblk)   kept points per block of LD_NT points
+  EdgeRec* edge;          // (B, 2, H)
 };
 
-struct __attribute__((aligned(16))) PixRec {
-  long long minz;  // smallest ordered(z) of the pixel's points
-  int first;       // smallest compacted index landing on the pixel
-  int last;        // largest one (-1: none)
+// max(z, 0) with the sign bit set, as a signed integer: negative for every z, increasing with z
+__device__ __forceinline__ long long encode_z(double z) {
+  const double zc = (z < 0.0) ? 0.0 : z;
+  return __builtin_bit_cast(long long, zc) | (long long)0x8000000000000000ull;
+}
+__device__ __forceinline__ double decode_z(long long e) {
+  return __builtin_bit_cast(double, e & 0x7fffffffffffffffLL);
+}
+
+struct Projected {
+  bool keep;
+  int x, y;
+  double z;
 };
-
-// order-preserving map double -> signed 64-bit integer (and back)
-__device__ __forceinline__ long long ordered(double z) {
-  const long long b = __builtin_bit_cast(long long, z);
-  return b >= 0 ? b : (b ^ 0x7fffffffffffffffLL);
-}
-__device__ __forceinline__ double unordered(long long k) {
-  return __builtin_bit_cast(double, k >= 0 ? k : (k ^ 0x7fffffffffffffffLL));
-}
-
-__global__ __launch_bounds__(LD_NT) void lidar_init_kernel(const LidarParams p) {
-  const int b = blockIdx.y;
-  const long hw = (long)p.H * p.W;
-  const long i = (long)blockIdx.x * LD_NT + threadIdx.x;
-  if (i < hw) {
-    PixRec r;
-    r.minz = 0x7fffffffffffffffLL;
-    r.first = 0x7fffffff;
-    r.last = -1;
-    p.rec[b * hw + i] = r;  // one 16-byte store
-  }
+// lines :119-134 for point i of scan b
+__device__ __forceinline__ Projected project_point(const LidarParams& p, int b, int i) {
+  Projected r;
+  const float4 v = reinterpret_cast<const float4*>(p.points)[(long)b * p.n_max + i];
+  const double X = (double)v.x, Y = (double)v.y, Z = (double)v.z;
+  const double* P = p.P + (long)b * 12;
+  const double c0 = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3];
+  const double c1 = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7];
+  const double c2 = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11];
+  const double x = rint(c0 / c2) - 1.0;
+  const double y = rint(c1 / c2) - 1.0;
+  r.keep = (v.x >= 0.f) && (x >= 0.0) && (y >= 0.0) && (x < (double)p.W) && (y < (double)p.H);
+  r.x = r.keep ? (int)x : 0;
+  r.y = r.keep ? (int)y : 0;
+  r.z = p.vel_depth ? X : c2;
+  return r;
 }
 
 // kept points of the calling block that precede this thread, and the block total
@@ -92,141 +109,137 @@ __device__ __forceinline__ int block_rank(bool keep, int* s_w, int& total) {
   return off + before;
 }
 
+// Pass 1 over the points (the map is zero): project, send every kept point of the inner columns
+// to its pixel, and leave the block's kept points (pixel, z), in scan order, and their number for
+// pass 2, which then touches kept points only.  Also clears the border records.
 __global__ __launch_bounds__(LD_NT) void lidar_project_kernel(const LidarParams p) {
   __shared__ int s_w[LD_NT / kWave];
   const int b = blockIdx.y;
   const int i = blockIdx.x * LD_NT + threadIdx.x;
   const int n = min(p.n_points[b], p.n_max);
-  bool keep = false;
+  for (int e = i; e < 2 * p.H; e += p.nblk * LD_NT) {
+    EdgeRec z;
+    z.nz = 0;
+    z.last1 = 0;
+    z.nfirst = 0;
+    p.edge[(long)b * 2 * p.H + e] = z;
+  }
+  Projected q;
+  q.keep = false;
   if (i < n) {
-    const float4 v = reinterpret_cast<const float4*>(p.points)[(long)b * p.n_max + i];
-    const double X = (double)v.x, Y = (double)v.y, Z = (double)v.z;
-    const double* P = p.P + (long)b * 12;
-    const double c0 = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3];
-    const double c1 = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7];
-    const double c2 = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11];
-    const double x = rint(c0 / c2) - 1.0;
-    const double y = rint(c1 / c2) - 1.0;
-    keep = (v.x >= 0.f) && (x >= 0.0) && (y >= 0.0) && (x < (double)p.W) && (y < (double)p.H);
-    p.loc[(long)b * p.n_max + i] = keep ? (int)y * p.W + (int)x : -1;
-    p.zbuf[(long)b * p.n_max + i] = p.vel_depth ? X : c2;
+    q = project_point(p, b, i);
+    if (q.keep && q.x > 0 && q.x < p.W - 1)
+      atomicMin(reinterpret_cast<long long*>(p.depth) + (long)b * p.H * p.W + (long)q.y * p.W + q.x, encode_z(q.z));
   }
   int total;
-  block_rank(keep, s_w, total);
+  const int rank = block_rank(q.keep, s_w, total);
+  if (q.keep) {
+    const long at = ((long)b * p.nblk + blockIdx.x) * LD_NT + rank;
+    p.loc[at] = q.y * p.W + q.x;
+    p.zbuf[at] = q.z;
+  }
   if (threadIdx.x == 0) p.blk_count[b * p.nblk + blockIdx.x] = total;
 }
 
-// exclusive scan of the per-block counts of one scan (one block per scan)
-__global__ __launch_bounds__(LD_NT) void lidar_scan_kernel(const LidarParams p) {
-  __shared__ int s_w[LD_NT / kWave];
-  __shared__ int s_carry;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int lane = tid & (kWave - 1), wid = tid / kWave;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < p.nblk; base += LD_NT) {
-    const int k = base + tid;
-    const int v = (k < p.nblk) ? p.blk_count[b * p.nblk + k] : 0;
-    int incl = v;  // inclusive scan within the wave
+// Pass 2, over the kept points block by block: the compacted list (scan order kept: a block's
+// offset is the sum of the counts of the blocks before it), the sign bits of the pixels pass 1
+// filled (every atomic of pass 1 has completed), and the records of the border columns, which
+// need the compacted index.
+// One wave per block of pass 1 (a launch of whole blocks per point block would be nothing but
+// their start-up latency: a point block keeps some thirty points).
+__global__ __launch_bounds__(LD_NT) void lidar_compact_kernel(const LidarParams p) {
+  const int b = blockIdx.y, lane = threadIdx.x & (kWave - 1);
+  const int blk = blockIdx.x * (LD_NT / kWave) + threadIdx.x / kWave;  // uniform over the wave
+  if (blk >= p.nblk) return;
+  // kept points of this scan in the point blocks before this one (integer sum: any order)
+  int offset = 0;
+  for (int k = lane; k < blk; k += kWave) offset += p.blk_count[b * p.nblk + k];
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int t = __shfl_up(incl, off, kWave);
-      if (lane >= off) incl += t;
-    }
-    if (lane == kWave - 1) s_w[wid] = incl;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_w[w];
-    const int carry = s_carry;
-    if (k < p.nblk) p.blk_count[b * p.nblk + k] = carry + woff + incl - v;
-    __syncthreads();
-    if (tid == LD_NT - 1) s_carry = carry + woff + incl;
-    __syncthreads();
-  }
-  if (tid == 0) p.n_valid[b] = s_carry;
-}
-
-__global__ __launch_bounds__(LD_NT) void lidar_scatter_kernel(const LidarParams p) {
-  __shared__ int s_w[LD_NT / kWave];
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * LD_NT + threadIdx.x;
-  const int n = min(p.n_points[b], p.n_max);
-  const long hw = (long)p.H * p.W;
-  int loc = -1;
-  if (i < n) loc = p.loc[(long)b * p.n_max + i];
-  int total;
-  const int j = p.blk_count[b * p.nblk + blockIdx.x] + block_rank(loc >= 0, s_w, total);
-  if (loc >= 0) {
-    const int y = loc / p.W, x = loc - y * p.W;
-    const double z = p.zbuf[(long)b * p.n_max + i];
+  for (int off = 32; off > 0; off >>= 1) offset += __shfl_xor(offset, off, kWave);
+  const int total = p.blk_count[b * p.nblk + blk];
+  for (int t = lane; t < total; t += kWave) {
+    const long at = ((long)b * p.nblk + blk) * LD_NT + t;
+    const int loc = p.loc[at];
+    const double z = p.zbuf[at];
+    const int y = (int)((unsigned)loc / (unsigned)p.W), x = loc - y * p.W;
+    const int j = offset + t;
     double* o = p.pts_im + ((long)b * p.n_max + j) * 3;
     o[0] = (double)x;
     o[1] = (double)y;
     o[2] = z;
-    PixRec* r = &p.rec[b * hw + loc];
-    atomicMax(&r->last, j);
-    atomicMin(&r->first, j);
-    atomicMin(&r->minz, ordered(z));
-  }
-}
-
-// One thread per kept point j: the last point of a pixel writes the pixel.  (Pixels
-// without a point keep the zero fill.)
-__global__ __launch_bounds__(LD_NT) void lidar_depth_kernel(const LidarParams p) {
-  const int b = blockIdx.y;
-  const long hw = (long)p.H * p.W;
-  const int j = blockIdx.x * LD_NT + threadIdx.x;
-  if (j >= p.n_valid[b]) return;
-  const double* pts = p.pts_im + (long)b * p.n_max * 3;
-  const int x = (int)pts[(long)j * 3 + 0], y = (int)pts[(long)j * 3 + 1];
-  const long loc = (long)y * p.W + x;
-  const PixRec* rec = p.rec + b * hw;
-  const PixRec r = rec[loc];
-  if (r.last != j) return;
-  double d = pts[(long)j * 3 + 2];
-  // The group of this pixel's key y * (W - 1) + x - 1: the pixel itself and, at the ends of a
-  // row, the pixel that shares the key ((y, W-1) with (y+1, 0)).  A group of more than one
-  // point writes its smallest z at the pixel of its first point.
-  int first = r.first, last = r.last;
-  long long minz = r.minz;
-  long other = -1;
-  if (x == p.W - 1 && y + 1 < p.H) other = loc + 1;
-  if (x == 0 && y > 0) other = loc - 1;
-  if (other >= 0) {
-    const PixRec o = rec[other];
-    if (o.last >= 0) {
-      first = min(first, o.first);
-      last = max(last, o.last);
-      minz = min(minz, o.minz);
+    if (x == 0 || x == p.W - 1) {
+      EdgeRec* r = &p.edge[((long)b * 2 + (x == 0 ? 0 : 1)) * p.H + y];
+      atomicMax(&r->last1, j + 1);
+      atomicMax(&r->nfirst, 0x7fffffff - j);
+      atomicMin(&r->nz, encode_z(z));
+    } else {
+      // (an atomic without a return value: the read-modify-write happens at the memory side and
+      // the lane does not wait for it; every point of the pixel leaves the same value)
+      unsigned long long* cell = reinterpret_cast<unsigned long long*>(p.depth) + (long)b * p.H * p.W + loc;
+      __hip_atomic_fetch_and(cell, 0x7fffffffffffffffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (first != last && first == r.first) d = unordered(minz);
-  p.depth[b * hw + loc] = (d < 0.0) ? 0.0 : d;
+  if (blk == p.nblk - 1 && lane == 0) p.n_valid[b] = offset + total;
+}
+
+// One thread per pixel of the two border columns.  The group of the pixel's key
+// y * (W - 1) + x - 1 is the pixel itself and the pixel that shares the key ((y, W-1) with
+// (y+1, 0)); a group of more than one point has its smallest z at the pixel of its first
+// point, every other pixel with points keeps the z of its last point (:137-147).
+__global__ __launch_bounds__(LD_NT) void lidar_border_kernel(const LidarParams p) {
+  const int b = blockIdx.y;
+  const int e = blockIdx.x * LD_NT + threadIdx.x;
+  if (e >= 2 * p.H) return;
+  const int side = e / p.H, y = e - side * p.H;
+  const EdgeRec* edge = p.edge + (long)b * 2 * p.H;
+  const EdgeRec r = edge[e];
+  if (r.last1 == 0) return;  // no point: the pixel keeps the zero fill
+  int first = 0x7fffffff - r.nfirst, last = r.last1 - 1;
+  long long nz = r.nz;
+  const int my_first = first;
+  // (W = 1 is refused by the host: a pixel is never in both border columns)
+  const int oy = side ? y + 1 : y - 1;
+  if (oy >= 0 && oy < p.H) {
+    const EdgeRec o = edge[(side ? 0 : 1) * p.H + oy];
+    if (o.last1 > 0) {
+      first = min(first, 0x7fffffff - o.nfirst);
+      last = max(last, o.last1 - 1);
+      nz = min(nz, o.nz);
+    }
+  }
+  double d;
+  if (first != last && first == my_first) {
+    d = decode_z(nz);
+  } else {
+    d = p.pts_im[((long)b * p.n_max + (r.last1 - 1)) * 3 + 2];
+    d = (d < 0.0) ? 0.0 : d;
+  }
+  p.depth[(long)b * p.H * p.W + (long)y * p.W + (side ? p.W - 1 : 0)] = d;
 }
 
 struct LidarLayout {
-  size_t loc, zbuf, blk, rec, total;
+  size_t loc, zbuf, blk, edge, total;
 };
 
 static LidarLayout lidar_layout(int B, int n_max, int H, int W) {
   LidarLayout L{};
-  const size_t hw = (size_t)H * W, nblk = (size_t)(n_max + LD_NT - 1) / LD_NT;
+  const size_t nblk = (size_t)(n_max + LD_NT - 1) / LD_NT;
   size_t o = 0;
   auto take = [&](size_t bytes) {
     const size_t at = o;
     o += align_up(bytes, 256);
     return at;
   };
-  L.zbuf = take(sizeof(double) * B * n_max);
-  L.rec = take(sizeof(PixRec) * B * hw);
-  L.loc = take(sizeof(int) * B * n_max);
+  L.zbuf = take(sizeof(double) * B * nblk * LD_NT);
+  L.loc = take(sizeof(int) * B * nblk * LD_NT);
+  L.edge = take(sizeof(EdgeRec) * B * 2 * H);
   L.blk = take(sizeof(int) * B * nblk);
   L.total = o;
   return L;
 }
 
 static bool lidar_shape_ok(int B, int n_max, int H, int W) {
-  return B >= 1 && B <= 65535 && n_max >= 1 && H >= 1 && W >= 2 && (long)H * W < (1L << 30) &&
+  return B >= 1 && B <= 65535 && n_max >= 1 && n_max < 0x7fffffff && H >= 1 && W >= 2 && (long)H * W < (1L << 30) &&
          (long)B * ((long)H * W + 1) < (1L << 31) && (long)B * n_max < (1L << 31);
 }
 
@@ -245,7 +258,7 @@ extern "C" int dw_lidar_project(int32_t B, int32_t n_max, int32_t H, int32_t W, 
                                 size_t workspace_bytes, void* stream) {
   if (!points || !n_points || !P || !pts_im || !n_valid || !depth || !workspace) return DW_ERR_NULL;
   if (!lidar_shape_ok(B, n_max, H, W)) return DW_ERR_SHAPE;
-  if (((uintptr_t)points & 15)) return DW_ERR_ARG;
+  if (((uintptr_t)points & 15) || ((uintptr_t)depth & 7)) return DW_ERR_ARG;
   const LidarLayout L = lidar_layout(B, n_max, H, W);
   if (workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return DW_ERR_WORKSPACE;
   char* ws = (char*)workspace;
@@ -254,16 +267,16 @@ extern "C" int dw_lidar_project(int32_t B, int32_t n_max, int32_t H, int32_t W, 
   p.nblk = (n_max + LD_NT - 1) / LD_NT;
   p.points = points; p.n_points = n_points; p.P = P;
   p.pts_im = pts_im; p.n_valid = n_valid; p.depth = depth;
-  p.loc = (int*)(ws + L.loc); p.zbuf = (double*)(ws + L.zbuf); p.blk_count = (int*)(ws + L.blk);
-  p.rec = (PixRec*)(ws + L.rec);
+  p.loc = (int*)(ws + L.loc);
+  p.zbuf = (double*)(ws + L.zbuf);
+  p.blk_count = (int*)(ws + L.blk);
+  p.edge = (EdgeRec*)(ws + L.edge);
   hipStream_t st = (hipStream_t)stream;
   const long hw = (long)H * W;
-  const dim3 gpix((unsigned)((hw + LD_NT - 1) / LD_NT), B), gpts(p.nblk, B);
-  lidar_init_kernel<<<gpix, LD_NT, 0, st>>>(p);
-  lidar_project_kernel<<<gpts, LD_NT, 0, st>>>(p);
-  lidar_scan_kernel<<<B, LD_NT, 0, st>>>(p);
-  lidar_scatter_kernel<<<gpts, LD_NT, 0, st>>>(p);
+  const dim3 gpts(p.nblk, B);
   if (hipMemsetAsync(depth, 0, sizeof(double) * (size_t)B * hw, st) != hipSuccess) return DW_ERR_LAUNCH;
-  lidar_depth_kernel<<<gpts, LD_NT, 0, st>>>(p);
+  lidar_project_kernel<<<gpts, LD_NT, 0, st>>>(p);
+  lidar_compact_kernel<<<dim3((p.nblk + LD_NT / kWave - 1) / (LD_NT / kWave), B), LD_NT, 0, st>>>(p);
+  lidar_border_kernel<<<dim3((2 * H + LD_NT - 1) / LD_NT, B), LD_NT, 0, st>>>(p);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }

@@ -65,6 +65,41 @@ def test_duplicates_and_key_collisions():
     assert np.array_equal(want_d, project_scan_loop(pts, P, (H, W)))   # literal Counter / np.where form
 
 
+@pytest.mark.parametrize("H,W,n,negative", [(7, 2, 300, False), (5, 3, 500, False), (6, 8, 400, True), (40, 2, 3000, True)])
+def test_border_columns_and_negative_depths(H, W, n, negative):
+    """Images so narrow that (nearly) every pixel is one of the two border columns, whose groups pair
+    (y, W-1) with (y+1, 0); and projective depths below zero, which the reference zeroes at the end
+    (load_dataset.py:148) after taking minima over them."""
+    from oracle.lidar import project_scan, project_scan_loop
+    sgn = -1.0 if negative else 1.0
+    # pixel = (left, up) / forward, depth = +-forward
+    P = np.array([[0.0, sgn, 0.0, 0.0], [0.0, 0.0, sgn, 0.0], [sgn, 0.0, 0.0, 0.0]])
+    g = np.random.default_rng(H * 100 + W)
+    z = g.uniform(1.0, 9.0, n)
+    if negative:   # a mix of signs on the same pixels: forward stays >= 0, the third row flips the sign of half
+        P = np.array([[0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [1.0, 0.0, 0.0, 0.0]])
+    x = g.integers(1, W + 1, n)
+    y = g.integers(1, H + 1, n)
+    pts = np.stack([z, x * z, y * z, np.ones(n)], 1).astype(np.float32)
+    scans = [pts, pts[::-1].copy()]      # the reversed order moves every "first" and "last"
+    pi, nv, d = _run(scans, P, (H, W))
+    for b, s in enumerate(scans):
+        want_pts, want_d = project_scan(s, P, (H, W))
+        assert nv[b] == len(want_pts) and np.array_equal(pi[b, :nv[b]], want_pts)
+        assert np.array_equal(d[b], want_d)
+        assert np.array_equal(want_d, project_scan_loop(s, P, (H, W)))
+    if negative:
+        # depths below zero: z = -forward through a projection whose third row is negated and whose
+        # first two rows are negated with it, so the pixels stay where they were
+        Pn = -P
+        pi, nv, d = _run(scans, Pn, (H, W))
+        for b, s in enumerate(scans):
+            want_pts, want_d = project_scan(s, Pn, (H, W))
+            assert nv[b] == len(want_pts) and nv[b] > 0 and (want_pts[:, 2] < 0).all()
+            assert np.array_equal(pi[b, :nv[b]], want_pts)
+            assert np.array_equal(d[b], want_d) and not d[b].any()
+
+
 def test_behind_camera_and_out_of_bounds_are_dropped():
     from depth_estimation_amd.lidar import synthetic_scan
     P = _P()
