@@ -72,6 +72,38 @@ def test_static_scratch_entry_point_refuses_what_does_not_fit_and_python_wrapper
     compute_loss_into(out, target, pred)
     want = compute_loss_terms(target, pred)
     assert torch.equal(out[:, 0], want["loss"]) and torch.equal(out[:, 3], want["smooth"])
+    # the wrapper raises on a problem beyond the scratch array: here through the batch size alone
+    # (one strip, one chunk, 32 bytes per sample: more than 32768 samples), 10 MB of inputs
+    Bb = 40000
+    assert 32 * Bb > _lib.DW_STATIC_SCRATCH_BYTES
     with pytest.raises(_lib.DepthwarpError):
-        compute_loss_into(torch.empty(B, 4, device="cuda"), torch.zeros(B, 1, H, W, device="cuda"),
-                          torch.zeros(B, 1, H, W, device="cuda"))
+        compute_loss_into(torch.empty(Bb, 4, device="cuda"), torch.zeros(Bb, 1, 8, 8, device="cuda"),
+                          torch.zeros(Bb, 1, 8, 8, device="cuda"))
+
+
+def test_static_scratch_entry_point_allocates_nothing_and_runs_under_graph_capture():
+    """No device memory is taken by the call (free memory of the device and the torch allocator's
+    books are the same before and after), and it can be recorded into a HIP graph -- where an
+    allocation would end the capture with an error -- and replayed on new inputs."""
+    from depth_estimation_amd.loss import compute_loss_into, compute_loss_terms
+    g = torch.Generator().manual_seed(9)
+    target, pred = torch.rand(2, 1, 375, 1242, generator=g).cuda(), torch.rand(2, 1, 256, 512, generator=g).cuda()
+    out = torch.empty(2, 4, device="cuda")
+    compute_loss_into(out, target, pred)            # first call on the device: outside capture
+    torch.cuda.synchronize()
+    free0, booked0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_allocated()
+    for _ in range(3):
+        compute_loss_into(out, target, pred)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0 and torch.cuda.memory_allocated() == booked0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        compute_loss_into(out, target, pred)
+    target.copy_(torch.rand(2, 1, 375, 1242, generator=g))
+    pred.copy_(torch.rand(2, 1, 256, 512, generator=g))
+    out.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    want = compute_loss_terms(target, pred)
+    for i, k in enumerate(("loss", "ssim_term", "l1", "smooth")):
+        assert torch.equal(out[:, i], want[k]), k
