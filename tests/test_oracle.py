@@ -195,3 +195,44 @@ def test_oracle_reproduces_color_gradient_golden():
         for f in range(2):
             assert np.allclose(got[f"grad_color{f}"], gold[f"grad_color{f}"], rtol=1e-4, atol=1e-10)
             assert np.abs(gold[f"grad_color{f}"]).max() > 0
+
+
+def test_compute_loss_oracle_against_scipy_ndimage():
+    """The third-party routines behind `Train.compute_loss` (kornia Sobel and SSIM window,
+    torchvision resize) are not importable here; their published definitions are restated in
+    `oracle/compute_loss.py`.  SciPy's ndimage states the same definitions independently --
+    `sobel` (derivative [-1, 0, 1] x smoothing [1, 2, 1], mode 'nearest' = replicate),
+    `correlate1d` with mode 'mirror' (= reflect without repeating the edge) and
+    `zoom(order=1, grid_mode=True)` (pixel-area bilinear resampling = align_corners=False) --
+    and must give the restatement's numbers in float64."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 1, 37, 53, generator=g, dtype=torch.float64)
+    a = x[0, 0].numpy()
+    e = cl.spatial_gradient(x)
+    assert np.allclose(e[0, 0, 0].numpy(), ndi.sobel(a, axis=1, mode="nearest") / 8.0, rtol=0, atol=1e-14)
+    assert np.allclose(e[0, 0, 1].numpy(), ndi.sobel(a, axis=0, mode="nearest") / 8.0, rtol=0, atol=1e-14)
+    w = cl.gaussian_window(7, 1.5, torch.float64)
+    want = ndi.correlate1d(ndi.correlate1d(a, w.numpy(), axis=0, mode="mirror"), w.numpy(), axis=1, mode="mirror")
+    got = cl._filter7(x, w[:, None] * w[None, :])[0, 0].numpy()
+    assert np.allclose(got, want, rtol=0, atol=1e-14)
+    # the window is the sampled Gaussian exp(-x^2 / (2 sigma^2)), normalised
+    ref_w = np.exp(-np.arange(-3, 4) ** 2 / (2 * 1.5 ** 2))
+    assert np.allclose(w.numpy(), ref_w / ref_w.sum(), rtol=0, atol=1e-15)
+    # resize of the reference's ground truth size to its training size, and an up-sampling
+    for (Ht, Wt), (H, W) in (((75, 124), (64, 96)), ((20, 31), (33, 40))):
+        t = torch.rand(1, 1, Ht, Wt, generator=g, dtype=torch.float64)
+        got = torch.nn.functional.interpolate(t, (H, W), mode="bilinear", align_corners=False)[0, 0].numpy()
+        want = ndi.zoom(t[0, 0].numpy(), (H / Ht, W / Wt), order=1, mode="nearest", grid_mode=True)
+        assert want.shape == (H, W) and np.allclose(got, want, rtol=0, atol=1e-12)
+    # and the SSIM map of two images from ndimage pieces against the restatement's loss
+    p = torch.rand(2, 1, 40, 56, generator=g, dtype=torch.float64)
+    t = torch.rand(2, 1, 40, 56, generator=g, dtype=torch.float64)
+    f = lambda v: ndi.correlate1d(ndi.correlate1d(v, w.numpy(), axis=0, mode="mirror"), w.numpy(), axis=1, mode="mirror")
+    for b in range(2):
+        u, v = p[b, 0].numpy(), t[b, 0].numpy()
+        mu1, mu2 = f(u), f(v)
+        s11, s22, s12 = f(u * u) - mu1 * mu1, f(v * v) - mu2 * mu2, f(u * v) - mu1 * mu2
+        ssim = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s11 + s22 + 9e-4) + 1e-12)
+        want = np.clip((1 - ssim) / 2, 0, 1).mean()
+        assert abs(float(cl.ssim_loss7(p[b:b + 1], t[b:b + 1])) - want) < 1e-13
