@@ -8,6 +8,59 @@
 // the same opcodes with a scalar-register operand -- and about 8.4 for transcendentals.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+// One loop body: the instruction of the mode in eight independent register chains (operand %n,
+// n = 0 .. 7), eight times over, as ONE asm statement (see above).
+#define CHAINS(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define BODY(OP) CHAINS(OP) CHAINS(OP) CHAINS(OP) CHAINS(OP) CHAINS(OP) CHAINS(OP) CHAINS(OP) CHAINS(OP)
+#define RUN(OP)                                                                                                   \
+  asm volatile(BODY(OP)                                                                                           \
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])   \
+               : "v"(m), "v"(c)                                                                                   \
+               : "vcc", "s10", "s11", "s20")
+// the instruction of every mode; %8 = m and %9 = c are vector registers, s20 / s[10:11] scalar ones
+#define OP0(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n\t"
+#define OP1(n) "v_mul_f32 %" #n ", %" #n ", %8\n\t"
+#define OP2(n) "v_add_f32 %" #n ", %" #n ", %9\n\t"
+#define OP3(n) "v_sub_f32 %" #n ", %" #n ", %9\n\t"
+#define OP4(n) "v_fmac_f32 %" #n ", %8, %9\n\t"
+#define OP5(n) "v_mov_b32 %" #n ", %8\n\t"
+#define OP6(n) "v_add_u32 %" #n ", %" #n ", %8\n\t"
+#define OP7(n) "v_sub_u32 %" #n ", %" #n ", %8\n\t"
+#define OP8(n) "v_and_b32 %" #n ", %" #n ", %8\n\t"
+#define OP9(n) "v_or_b32 %" #n ", %" #n ", %8\n\t"
+#define OP10(n) "v_xor_b32 %" #n ", %" #n ", %8\n\t"
+#define OP11(n) "v_ashrrev_i32 %" #n ", 1, %" #n "\n\t"
+#define OP12(n) "v_mul_f32 %" #n ", 0.5, %" #n "\n\t"
+#define OP13(n) "v_mul_f32 %" #n ", 0x3f9e0419, %" #n "\n\t"
+#define OP14(n) "v_fmaak_f32 %" #n ", %" #n ", %8, 0x3f9e0419\n\t"
+#define OP15(n) "v_add_f32 %" #n ", -%" #n ", %8\n\t"
+#define OP16(n) "v_sub_f32 %" #n ", |%" #n "|, %8\n\t"
+#define OP17(n) "v_mul_f32 %" #n ", s20, %" #n "\n\t"
+#define OP18(n) "v_add_f32 %" #n ", s20, %" #n "\n\t"
+#define OP19(n) "v_fma_f32 %" #n ", %" #n ", s20, %9\n\t"
+#define OP20(n) "v_add_u32 %" #n ", s20, %" #n "\n\t"
+#define OP21(n) "v_mov_b32 %" #n ", s20\n\t"
+#define OP22(n) "v_cndmask_b32 %" #n ", %" #n ", %8, s[10:11]\n\t"
+#define OP23(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n\t"
+#define OP24(n) "v_min_f32 %" #n ", %" #n ", %8\n\t"
+#define OP25(n) "v_max_f32 %" #n ", %" #n ", %8\n\t"
+#define OP26(n) "v_med3_f32 %" #n ", %" #n ", %8, %9\n\t"
+#define OP27(n) "v_floor_f32 %" #n ", %" #n "\n\t"
+#define OP28(n) "v_cvt_i32_f32 %" #n ", %" #n "\n\t"
+#define OP29(n) "v_cvt_f32_i32 %" #n ", %" #n "\n\t"
+#define OP30(n) "v_min_i32 %" #n ", %" #n ", %8\n\t"
+#define OP31(n) "v_lshlrev_b32 %" #n ", 1, %" #n "\n\t"
+#define OP32(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n\t"
+#define OP33(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n\t"
+#define OP34(n) "v_bfe_u32 %" #n ", %" #n ", 4, 8\n\t"
+#define OP35(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n\t"
+#define OP36(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n\t"
+#define OP37(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n\t"
+#define OP38(n) "v_div_fixup_f32 %" #n ", %" #n ", %8, %9\n\t"
+#define OP39(n) "v_ldexp_f32 %" #n ", %" #n ", 1\n\t"
+#define OP40(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define OP41(n) "v_rcp_f32 %" #n ", %" #n "\n\t"
+#define OP42(n) "v_exp_f32 %" #n ", %" #n "\n\t"
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
   float a[8];
@@ -15,2929 +68,91 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   const float m = 1.0001f, c = 1e-6f;
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0)
-      asm volatile(
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      "v_fma_f32 %0, %0, %8, %9\n\t"
-      "v_fma_f32 %1, %1, %8, %9\n\t"
-      "v_fma_f32 %2, %2, %8, %9\n\t"
-      "v_fma_f32 %3, %3, %8, %9\n\t"
-      "v_fma_f32 %4, %4, %8, %9\n\t"
-      "v_fma_f32 %5, %5, %8, %9\n\t"
-      "v_fma_f32 %6, %6, %8, %9\n\t"
-      "v_fma_f32 %7, %7, %8, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 1)
-      asm volatile(
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      "v_mul_f32 %0, %0, %8\n\t"
-      "v_mul_f32 %1, %1, %8\n\t"
-      "v_mul_f32 %2, %2, %8\n\t"
-      "v_mul_f32 %3, %3, %8\n\t"
-      "v_mul_f32 %4, %4, %8\n\t"
-      "v_mul_f32 %5, %5, %8\n\t"
-      "v_mul_f32 %6, %6, %8\n\t"
-      "v_mul_f32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 2)
-      asm volatile(
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      "v_add_f32 %0, %0, %9\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %9\n\t"
-      "v_add_f32 %3, %3, %9\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %9\n\t"
-      "v_add_f32 %6, %6, %9\n\t"
-      "v_add_f32 %7, %7, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 3)
-      asm volatile(
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      "v_sub_f32 %0, %0, %9\n\t"
-      "v_sub_f32 %1, %1, %9\n\t"
-      "v_sub_f32 %2, %2, %9\n\t"
-      "v_sub_f32 %3, %3, %9\n\t"
-      "v_sub_f32 %4, %4, %9\n\t"
-      "v_sub_f32 %5, %5, %9\n\t"
-      "v_sub_f32 %6, %6, %9\n\t"
-      "v_sub_f32 %7, %7, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 4)
-      asm volatile(
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      "v_fmac_f32 %0, %8, %9\n\t"
-      "v_fmac_f32 %1, %8, %9\n\t"
-      "v_fmac_f32 %2, %8, %9\n\t"
-      "v_fmac_f32 %3, %8, %9\n\t"
-      "v_fmac_f32 %4, %8, %9\n\t"
-      "v_fmac_f32 %5, %8, %9\n\t"
-      "v_fmac_f32 %6, %8, %9\n\t"
-      "v_fmac_f32 %7, %8, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 5)
-      asm volatile(
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      "v_mov_b32 %0, %8\n\t"
-      "v_mov_b32 %1, %8\n\t"
-      "v_mov_b32 %2, %8\n\t"
-      "v_mov_b32 %3, %8\n\t"
-      "v_mov_b32 %4, %8\n\t"
-      "v_mov_b32 %5, %8\n\t"
-      "v_mov_b32 %6, %8\n\t"
-      "v_mov_b32 %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 6)
-      asm volatile(
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      "v_add_u32 %0, %0, %8\n\t"
-      "v_add_u32 %1, %1, %8\n\t"
-      "v_add_u32 %2, %2, %8\n\t"
-      "v_add_u32 %3, %3, %8\n\t"
-      "v_add_u32 %4, %4, %8\n\t"
-      "v_add_u32 %5, %5, %8\n\t"
-      "v_add_u32 %6, %6, %8\n\t"
-      "v_add_u32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 7)
-      asm volatile(
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      "v_sub_u32 %0, %0, %8\n\t"
-      "v_sub_u32 %1, %1, %8\n\t"
-      "v_sub_u32 %2, %2, %8\n\t"
-      "v_sub_u32 %3, %3, %8\n\t"
-      "v_sub_u32 %4, %4, %8\n\t"
-      "v_sub_u32 %5, %5, %8\n\t"
-      "v_sub_u32 %6, %6, %8\n\t"
-      "v_sub_u32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 8)
-      asm volatile(
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      "v_and_b32 %0, %0, %8\n\t"
-      "v_and_b32 %1, %1, %8\n\t"
-      "v_and_b32 %2, %2, %8\n\t"
-      "v_and_b32 %3, %3, %8\n\t"
-      "v_and_b32 %4, %4, %8\n\t"
-      "v_and_b32 %5, %5, %8\n\t"
-      "v_and_b32 %6, %6, %8\n\t"
-      "v_and_b32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 9)
-      asm volatile(
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      "v_or_b32 %0, %0, %8\n\t"
-      "v_or_b32 %1, %1, %8\n\t"
-      "v_or_b32 %2, %2, %8\n\t"
-      "v_or_b32 %3, %3, %8\n\t"
-      "v_or_b32 %4, %4, %8\n\t"
-      "v_or_b32 %5, %5, %8\n\t"
-      "v_or_b32 %6, %6, %8\n\t"
-      "v_or_b32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 10)
-      asm volatile(
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      "v_xor_b32 %0, %0, %8\n\t"
-      "v_xor_b32 %1, %1, %8\n\t"
-      "v_xor_b32 %2, %2, %8\n\t"
-      "v_xor_b32 %3, %3, %8\n\t"
-      "v_xor_b32 %4, %4, %8\n\t"
-      "v_xor_b32 %5, %5, %8\n\t"
-      "v_xor_b32 %6, %6, %8\n\t"
-      "v_xor_b32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 11)
-      asm volatile(
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      "v_ashrrev_i32 %0, 1, %0\n\t"
-      "v_ashrrev_i32 %1, 1, %1\n\t"
-      "v_ashrrev_i32 %2, 1, %2\n\t"
-      "v_ashrrev_i32 %3, 1, %3\n\t"
-      "v_ashrrev_i32 %4, 1, %4\n\t"
-      "v_ashrrev_i32 %5, 1, %5\n\t"
-      "v_ashrrev_i32 %6, 1, %6\n\t"
-      "v_ashrrev_i32 %7, 1, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 12)
-      asm volatile(
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      "v_mul_f32 %0, 0.5, %0\n\t"
-      "v_mul_f32 %1, 0.5, %1\n\t"
-      "v_mul_f32 %2, 0.5, %2\n\t"
-      "v_mul_f32 %3, 0.5, %3\n\t"
-      "v_mul_f32 %4, 0.5, %4\n\t"
-      "v_mul_f32 %5, 0.5, %5\n\t"
-      "v_mul_f32 %6, 0.5, %6\n\t"
-      "v_mul_f32 %7, 0.5, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 13)
-      asm volatile(
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      "v_mul_f32 %0, 0x3f9e0419, %0\n\t"
-      "v_mul_f32 %1, 0x3f9e0419, %1\n\t"
-      "v_mul_f32 %2, 0x3f9e0419, %2\n\t"
-      "v_mul_f32 %3, 0x3f9e0419, %3\n\t"
-      "v_mul_f32 %4, 0x3f9e0419, %4\n\t"
-      "v_mul_f32 %5, 0x3f9e0419, %5\n\t"
-      "v_mul_f32 %6, 0x3f9e0419, %6\n\t"
-      "v_mul_f32 %7, 0x3f9e0419, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 14)
-      asm volatile(
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %0, %0, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %1, %1, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %2, %2, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %3, %3, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %4, %4, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %5, %5, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %6, %6, %8, 0x3f9e0419\n\t"
-      "v_fmaak_f32 %7, %7, %8, 0x3f9e0419\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 15)
-      asm volatile(
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      "v_add_f32 %0, -%0, %8\n\t"
-      "v_add_f32 %1, -%1, %8\n\t"
-      "v_add_f32 %2, -%2, %8\n\t"
-      "v_add_f32 %3, -%3, %8\n\t"
-      "v_add_f32 %4, -%4, %8\n\t"
-      "v_add_f32 %5, -%5, %8\n\t"
-      "v_add_f32 %6, -%6, %8\n\t"
-      "v_add_f32 %7, -%7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 16)
-      asm volatile(
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      "v_sub_f32 %0, |%0|, %8\n\t"
-      "v_sub_f32 %1, |%1|, %8\n\t"
-      "v_sub_f32 %2, |%2|, %8\n\t"
-      "v_sub_f32 %3, |%3|, %8\n\t"
-      "v_sub_f32 %4, |%4|, %8\n\t"
-      "v_sub_f32 %5, |%5|, %8\n\t"
-      "v_sub_f32 %6, |%6|, %8\n\t"
-      "v_sub_f32 %7, |%7|, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 17)
-      asm volatile(
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      "v_mul_f32 %0, s20, %0\n\t"
-      "v_mul_f32 %1, s20, %1\n\t"
-      "v_mul_f32 %2, s20, %2\n\t"
-      "v_mul_f32 %3, s20, %3\n\t"
-      "v_mul_f32 %4, s20, %4\n\t"
-      "v_mul_f32 %5, s20, %5\n\t"
-      "v_mul_f32 %6, s20, %6\n\t"
-      "v_mul_f32 %7, s20, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 18)
-      asm volatile(
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      "v_add_f32 %0, s20, %0\n\t"
-      "v_add_f32 %1, s20, %1\n\t"
-      "v_add_f32 %2, s20, %2\n\t"
-      "v_add_f32 %3, s20, %3\n\t"
-      "v_add_f32 %4, s20, %4\n\t"
-      "v_add_f32 %5, s20, %5\n\t"
-      "v_add_f32 %6, s20, %6\n\t"
-      "v_add_f32 %7, s20, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 19)
-      asm volatile(
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      "v_fma_f32 %0, %0, s20, %9\n\t"
-      "v_fma_f32 %1, %1, s20, %9\n\t"
-      "v_fma_f32 %2, %2, s20, %9\n\t"
-      "v_fma_f32 %3, %3, s20, %9\n\t"
-      "v_fma_f32 %4, %4, s20, %9\n\t"
-      "v_fma_f32 %5, %5, s20, %9\n\t"
-      "v_fma_f32 %6, %6, s20, %9\n\t"
-      "v_fma_f32 %7, %7, s20, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 20)
-      asm volatile(
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      "v_add_u32 %0, s20, %0\n\t"
-      "v_add_u32 %1, s20, %1\n\t"
-      "v_add_u32 %2, s20, %2\n\t"
-      "v_add_u32 %3, s20, %3\n\t"
-      "v_add_u32 %4, s20, %4\n\t"
-      "v_add_u32 %5, s20, %5\n\t"
-      "v_add_u32 %6, s20, %6\n\t"
-      "v_add_u32 %7, s20, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 21)
-      asm volatile(
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      "v_mov_b32 %0, s20\n\t"
-      "v_mov_b32 %1, s20\n\t"
-      "v_mov_b32 %2, s20\n\t"
-      "v_mov_b32 %3, s20\n\t"
-      "v_mov_b32 %4, s20\n\t"
-      "v_mov_b32 %5, s20\n\t"
-      "v_mov_b32 %6, s20\n\t"
-      "v_mov_b32 %7, s20\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 22)
-      asm volatile(
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %0, %0, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %1, %1, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %2, %2, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %3, %3, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %4, %4, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %5, %5, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %6, %6, %8, s[10:11]\n\t"
-      "v_cndmask_b32 %7, %7, %8, s[10:11]\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 23)
-      asm volatile(
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      "v_cmp_lt_f32 vcc, %0, %8\n\t"
-      "v_cmp_lt_f32 vcc, %1, %8\n\t"
-      "v_cmp_lt_f32 vcc, %2, %8\n\t"
-      "v_cmp_lt_f32 vcc, %3, %8\n\t"
-      "v_cmp_lt_f32 vcc, %4, %8\n\t"
-      "v_cmp_lt_f32 vcc, %5, %8\n\t"
-      "v_cmp_lt_f32 vcc, %6, %8\n\t"
-      "v_cmp_lt_f32 vcc, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 24)
-      asm volatile(
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      "v_min_f32 %0, %0, %8\n\t"
-      "v_min_f32 %1, %1, %8\n\t"
-      "v_min_f32 %2, %2, %8\n\t"
-      "v_min_f32 %3, %3, %8\n\t"
-      "v_min_f32 %4, %4, %8\n\t"
-      "v_min_f32 %5, %5, %8\n\t"
-      "v_min_f32 %6, %6, %8\n\t"
-      "v_min_f32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 25)
-      asm volatile(
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      "v_max_f32 %0, %0, %8\n\t"
-      "v_max_f32 %1, %1, %8\n\t"
-      "v_max_f32 %2, %2, %8\n\t"
-      "v_max_f32 %3, %3, %8\n\t"
-      "v_max_f32 %4, %4, %8\n\t"
-      "v_max_f32 %5, %5, %8\n\t"
-      "v_max_f32 %6, %6, %8\n\t"
-      "v_max_f32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 26)
-      asm volatile(
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      "v_med3_f32 %0, %0, %8, %9\n\t"
-      "v_med3_f32 %1, %1, %8, %9\n\t"
-      "v_med3_f32 %2, %2, %8, %9\n\t"
-      "v_med3_f32 %3, %3, %8, %9\n\t"
-      "v_med3_f32 %4, %4, %8, %9\n\t"
-      "v_med3_f32 %5, %5, %8, %9\n\t"
-      "v_med3_f32 %6, %6, %8, %9\n\t"
-      "v_med3_f32 %7, %7, %8, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 27)
-      asm volatile(
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      "v_floor_f32 %0, %0\n\t"
-      "v_floor_f32 %1, %1\n\t"
-      "v_floor_f32 %2, %2\n\t"
-      "v_floor_f32 %3, %3\n\t"
-      "v_floor_f32 %4, %4\n\t"
-      "v_floor_f32 %5, %5\n\t"
-      "v_floor_f32 %6, %6\n\t"
-      "v_floor_f32 %7, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 28)
-      asm volatile(
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      "v_cvt_i32_f32 %0, %0\n\t"
-      "v_cvt_i32_f32 %1, %1\n\t"
-      "v_cvt_i32_f32 %2, %2\n\t"
-      "v_cvt_i32_f32 %3, %3\n\t"
-      "v_cvt_i32_f32 %4, %4\n\t"
-      "v_cvt_i32_f32 %5, %5\n\t"
-      "v_cvt_i32_f32 %6, %6\n\t"
-      "v_cvt_i32_f32 %7, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 29)
-      asm volatile(
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      "v_cvt_f32_i32 %0, %0\n\t"
-      "v_cvt_f32_i32 %1, %1\n\t"
-      "v_cvt_f32_i32 %2, %2\n\t"
-      "v_cvt_f32_i32 %3, %3\n\t"
-      "v_cvt_f32_i32 %4, %4\n\t"
-      "v_cvt_f32_i32 %5, %5\n\t"
-      "v_cvt_f32_i32 %6, %6\n\t"
-      "v_cvt_f32_i32 %7, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 30)
-      asm volatile(
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      "v_min_i32 %0, %0, %8\n\t"
-      "v_min_i32 %1, %1, %8\n\t"
-      "v_min_i32 %2, %2, %8\n\t"
-      "v_min_i32 %3, %3, %8\n\t"
-      "v_min_i32 %4, %4, %8\n\t"
-      "v_min_i32 %5, %5, %8\n\t"
-      "v_min_i32 %6, %6, %8\n\t"
-      "v_min_i32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 31)
-      asm volatile(
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      "v_lshlrev_b32 %0, 1, %0\n\t"
-      "v_lshlrev_b32 %1, 1, %1\n\t"
-      "v_lshlrev_b32 %2, 1, %2\n\t"
-      "v_lshlrev_b32 %3, 1, %3\n\t"
-      "v_lshlrev_b32 %4, 1, %4\n\t"
-      "v_lshlrev_b32 %5, 1, %5\n\t"
-      "v_lshlrev_b32 %6, 1, %6\n\t"
-      "v_lshlrev_b32 %7, 1, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 32)
-      asm volatile(
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      "v_lshl_add_u32 %0, %0, 2, %8\n\t"
-      "v_lshl_add_u32 %1, %1, 2, %8\n\t"
-      "v_lshl_add_u32 %2, %2, 2, %8\n\t"
-      "v_lshl_add_u32 %3, %3, 2, %8\n\t"
-      "v_lshl_add_u32 %4, %4, 2, %8\n\t"
-      "v_lshl_add_u32 %5, %5, 2, %8\n\t"
-      "v_lshl_add_u32 %6, %6, 2, %8\n\t"
-      "v_lshl_add_u32 %7, %7, 2, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 33)
-      asm volatile(
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      "v_add3_u32 %0, %0, %8, %9\n\t"
-      "v_add3_u32 %1, %1, %8, %9\n\t"
-      "v_add3_u32 %2, %2, %8, %9\n\t"
-      "v_add3_u32 %3, %3, %8, %9\n\t"
-      "v_add3_u32 %4, %4, %8, %9\n\t"
-      "v_add3_u32 %5, %5, %8, %9\n\t"
-      "v_add3_u32 %6, %6, %8, %9\n\t"
-      "v_add3_u32 %7, %7, %8, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 34)
-      asm volatile(
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      "v_bfe_u32 %0, %0, 4, 8\n\t"
-      "v_bfe_u32 %1, %1, 4, 8\n\t"
-      "v_bfe_u32 %2, %2, 4, 8\n\t"
-      "v_bfe_u32 %3, %3, 4, 8\n\t"
-      "v_bfe_u32 %4, %4, 4, 8\n\t"
-      "v_bfe_u32 %5, %5, 4, 8\n\t"
-      "v_bfe_u32 %6, %6, 4, 8\n\t"
-      "v_bfe_u32 %7, %7, 4, 8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 35)
-      asm volatile(
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      "v_mul_u32_u24 %0, %0, %8\n\t"
-      "v_mul_u32_u24 %1, %1, %8\n\t"
-      "v_mul_u32_u24 %2, %2, %8\n\t"
-      "v_mul_u32_u24 %3, %3, %8\n\t"
-      "v_mul_u32_u24 %4, %4, %8\n\t"
-      "v_mul_u32_u24 %5, %5, %8\n\t"
-      "v_mul_u32_u24 %6, %6, %8\n\t"
-      "v_mul_u32_u24 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 36)
-      asm volatile(
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      "v_mad_u32_u24 %0, %0, %8, %9\n\t"
-      "v_mad_u32_u24 %1, %1, %8, %9\n\t"
-      "v_mad_u32_u24 %2, %2, %8, %9\n\t"
-      "v_mad_u32_u24 %3, %3, %8, %9\n\t"
-      "v_mad_u32_u24 %4, %4, %8, %9\n\t"
-      "v_mad_u32_u24 %5, %5, %8, %9\n\t"
-      "v_mad_u32_u24 %6, %6, %8, %9\n\t"
-      "v_mad_u32_u24 %7, %7, %8, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 37)
-      asm volatile(
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      "v_mul_lo_u32 %0, %0, %8\n\t"
-      "v_mul_lo_u32 %1, %1, %8\n\t"
-      "v_mul_lo_u32 %2, %2, %8\n\t"
-      "v_mul_lo_u32 %3, %3, %8\n\t"
-      "v_mul_lo_u32 %4, %4, %8\n\t"
-      "v_mul_lo_u32 %5, %5, %8\n\t"
-      "v_mul_lo_u32 %6, %6, %8\n\t"
-      "v_mul_lo_u32 %7, %7, %8\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 38)
-      asm volatile(
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      "v_div_fixup_f32 %0, %0, %8, %9\n\t"
-      "v_div_fixup_f32 %1, %1, %8, %9\n\t"
-      "v_div_fixup_f32 %2, %2, %8, %9\n\t"
-      "v_div_fixup_f32 %3, %3, %8, %9\n\t"
-      "v_div_fixup_f32 %4, %4, %8, %9\n\t"
-      "v_div_fixup_f32 %5, %5, %8, %9\n\t"
-      "v_div_fixup_f32 %6, %6, %8, %9\n\t"
-      "v_div_fixup_f32 %7, %7, %8, %9\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 39)
-      asm volatile(
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      "v_ldexp_f32 %0, %0, 1\n\t"
-      "v_ldexp_f32 %1, %1, 1\n\t"
-      "v_ldexp_f32 %2, %2, 1\n\t"
-      "v_ldexp_f32 %3, %3, 1\n\t"
-      "v_ldexp_f32 %4, %4, 1\n\t"
-      "v_ldexp_f32 %5, %5, 1\n\t"
-      "v_ldexp_f32 %6, %6, 1\n\t"
-      "v_ldexp_f32 %7, %7, 1\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 40)
-      asm volatile(
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 41)
-      asm volatile(
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      "v_rcp_f32 %0, %0\n\t"
-      "v_rcp_f32 %1, %1\n\t"
-      "v_rcp_f32 %2, %2\n\t"
-      "v_rcp_f32 %3, %3\n\t"
-      "v_rcp_f32 %4, %4\n\t"
-      "v_rcp_f32 %5, %5\n\t"
-      "v_rcp_f32 %6, %6\n\t"
-      "v_rcp_f32 %7, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
-    if (MODE == 42)
-      asm volatile(
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      "v_exp_f32 %0, %0\n\t"
-      "v_exp_f32 %1, %1\n\t"
-      "v_exp_f32 %2, %2\n\t"
-      "v_exp_f32 %3, %3\n\t"
-      "v_exp_f32 %4, %4\n\t"
-      "v_exp_f32 %5, %5\n\t"
-      "v_exp_f32 %6, %6\n\t"
-      "v_exp_f32 %7, %7\n\t"
-      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-      : "v"(m), "v"(c) : "vcc", "s10", "s11", "s20");
+      RUN(OP0);
+    else if (MODE == 1)
+      RUN(OP1);
+    else if (MODE == 2)
+      RUN(OP2);
+    else if (MODE == 3)
+      RUN(OP3);
+    else if (MODE == 4)
+      RUN(OP4);
+    else if (MODE == 5)
+      RUN(OP5);
+    else if (MODE == 6)
+      RUN(OP6);
+    else if (MODE == 7)
+      RUN(OP7);
+    else if (MODE == 8)
+      RUN(OP8);
+    else if (MODE == 9)
+      RUN(OP9);
+    else if (MODE == 10)
+      RUN(OP10);
+    else if (MODE == 11)
+      RUN(OP11);
+    else if (MODE == 12)
+      RUN(OP12);
+    else if (MODE == 13)
+      RUN(OP13);
+    else if (MODE == 14)
+      RUN(OP14);
+    else if (MODE == 15)
+      RUN(OP15);
+    else if (MODE == 16)
+      RUN(OP16);
+    else if (MODE == 17)
+      RUN(OP17);
+    else if (MODE == 18)
+      RUN(OP18);
+    else if (MODE == 19)
+      RUN(OP19);
+    else if (MODE == 20)
+      RUN(OP20);
+    else if (MODE == 21)
+      RUN(OP21);
+    else if (MODE == 22)
+      RUN(OP22);
+    else if (MODE == 23)
+      RUN(OP23);
+    else if (MODE == 24)
+      RUN(OP24);
+    else if (MODE == 25)
+      RUN(OP25);
+    else if (MODE == 26)
+      RUN(OP26);
+    else if (MODE == 27)
+      RUN(OP27);
+    else if (MODE == 28)
+      RUN(OP28);
+    else if (MODE == 29)
+      RUN(OP29);
+    else if (MODE == 30)
+      RUN(OP30);
+    else if (MODE == 31)
+      RUN(OP31);
+    else if (MODE == 32)
+      RUN(OP32);
+    else if (MODE == 33)
+      RUN(OP33);
+    else if (MODE == 34)
+      RUN(OP34);
+    else if (MODE == 35)
+      RUN(OP35);
+    else if (MODE == 36)
+      RUN(OP36);
+    else if (MODE == 37)
+      RUN(OP37);
+    else if (MODE == 38)
+      RUN(OP38);
+    else if (MODE == 39)
+      RUN(OP39);
+    else if (MODE == 40)
+      RUN(OP40);
+    else if (MODE == 41)
+      RUN(OP41);
+    else if (MODE == 42)
+      RUN(OP42);
   }
   float s = 0;
   for (int i = 0; i < 8; ++i) s += a[i];
