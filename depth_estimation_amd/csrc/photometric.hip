@@ -100,6 +100,19 @@ struct ScaleLayout {
   long pix_off[DW_MAX_SCALES + 1];  // prefix sum of B * Hs * Ws
 };
 
+// Element `i` of a per-scale array of the kernel arguments.  The arguments live in constant
+// memory; an index known only at run time is a scalar load of its own, and a block that first
+// decodes "which scale am I" through three or four of them, one depending on the other, spends
+// its first microsecond there -- as long as the short map blocks take for their work.  Reading
+// all entries (fixed offsets: one wide load when the kernel starts) and selecting costs nothing.
+template <typename T, int N>
+__device__ __forceinline__ T sel(const T (&a)[N], int i) {
+  T v = a[0];
+#pragma unroll
+  for (int j = 1; j < N; ++j) v = (i == j) ? a[j] : v;
+  return v;
+}
+
 struct PhotoParams {
   int B, H, W, S;
   int tilesX, tilesY;  // of the kernel being launched
@@ -228,6 +241,7 @@ struct SampleAddr {
   unsigned vb;
 };
 typedef float PairU __attribute__((ext_vector_type(2), aligned(4)));  // 8 bytes, dword aligned
+typedef float QuadU __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes, dword aligned
 struct SampleTaps {
   PairU n[3], s[3];  // upper and lower pair of every channel
 };
@@ -407,6 +421,9 @@ __device__ __forceinline__ float rowsum3(const float cs[WW], int p) {
 constexpr int DU_NT = 256;
 // PX pixels of a row per thread (4 when the width allows 16-byte stores, else 1); all taps of a
 // thread are loaded before the first is used.  `blk`: block of sample `b`.
+// (Reading the taps of the four pixels as one dword-aligned 16-byte load per tap row and picking
+// them out of it -- 7 loads per thread instead of 52 -- is slower: 28 against 21 us for the
+// launch; the lanes' 16-byte windows overlap and are not aligned.)
 template <int PX>
 __device__ __forceinline__ void depth_up_block(const PhotoParams& p, int b, int blk) {
   const int H = p.H, W = p.W;
@@ -427,7 +444,13 @@ __device__ __forceinline__ void depth_up_block(const PhotoParams& p, int b, int 
 #pragma unroll
       for (int k = 0; k < PX; ++k) {
         if (s == 0) {  // not up-sampled
-          v[s][k][0] = v[s][k][1] = v[s][k][2] = v[s][k][3] = d[(long)y * ws + x + k];
+          if (PX == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(d + (long)y * ws + x);
+            const float e = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
+            v[s][k][0] = v[s][k][1] = v[s][k][2] = v[s][k][3] = e;
+          } else {
+            v[s][k][0] = v[s][k][1] = v[s][k][2] = v[s][k][3] = d[(long)y * ws + x + k];
+          }
           wx0[s][k] = 1.f, wx1[s][k] = 0.f;
         } else {
           const Taps tx = upsample_taps(x + k, ws, p.rsx[s]);
@@ -1294,10 +1317,12 @@ __global__ __launch_bounds__(Geom<true>::NT, Geom<true>::MINW) void photo_tile_c
 __device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, int blk, int& s,
                                                  int& b, int& chunk) {
   s = 0;
-  while (s + 1 < S && blk >= L.blk_off[s + 1]) ++s;
-  const int r = blk - L.blk_off[s];
-  b = r / L.nblk[s];
-  chunk = r - b * L.nblk[s];
+#pragma unroll
+  for (int j = 1; j < DW_MAX_SCALES; ++j) s += (j < S && blk >= L.blk_off[j]) ? 1 : 0;  // blk_off ascends
+  const int r = blk - sel(L.blk_off, s);
+  const int nb = sel(L.nblk, s);
+  b = r / nb;
+  chunk = r - b * nb;
 }
 
 // ------------------------------------------------- edge-aware smoothness
@@ -1312,8 +1337,9 @@ __device__ __forceinline__ void decode_map_block(const ScaleLayout& L, int S, in
 template <bool GRAD>
 __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
   static_assert(SM_NT == DU_NT, "the depth blocks run in this kernel's launch");
-  if ((int)blockIdx.x >= p.L.blk_off[p.S]) {  // the blocks behind the smoothness blocks: depth maps
-    const int k = (int)blockIdx.x - p.L.blk_off[p.S];
+  const int n_smooth_blocks = sel(p.L.blk_off, p.S);
+  if ((int)blockIdx.x >= n_smooth_blocks) {  // the blocks behind the smoothness blocks: depth maps
+    const int k = (int)blockIdx.x - n_smooth_blocks;
     if (p.du_px == 4)
       depth_up_block<4>(p, k / p.du_nblk, k % p.du_nblk);
     else
@@ -1322,10 +1348,11 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
   }
   int s, b, chunk;
   decode_map_block(p.L, p.S, blockIdx.x, s, b, chunk);
-  const int hs = p.L.Hs[s], ws = p.L.Ws[s];
+  const int hs = p.H >> s, ws = p.W >> s;
   const long n = (long)hs * ws;
-  const float* d = p.disp[s] + (long)b * n;
-  const float* I = p.pyr[s] + (long)b * 3 * n;
+  const float* d = sel(p.disp, s) + (long)b * n;
+  const float* I = sel(p.pyr, s) + (long)b * 3 * n;
+  const long pix_off = sel(p.L.pix_off, s);
   const float icx = 1.0f / ((float)p.B * hs * (ws - 1));
   const float icy = 1.0f / ((float)p.B * (hs - 1) * ws);
   float lx = 0.f, ly = 0.f, gd = 0.f, sd = 0.f;
@@ -1388,7 +1415,7 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
         if (GRAD) gd = fmaf(G, dc, gd);
       }
       if (GRAD)
-        *reinterpret_cast<float4*>(p.sm_G + p.L.pix_off[s] + (long)b * n + i0) =
+        *reinterpret_cast<float4*>(p.sm_G + pix_off + (long)b * n + i0) =
             make_float4(Gv[0], Gv[1], Gv[2], Gv[3]);
     }
   } else {
@@ -1424,7 +1451,7 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
     }
     sd += dc;
     if (GRAD) {
-      p.sm_G[p.L.pix_off[s] + (long)b * n + i] = G;
+      p.sm_G[pix_off + (long)b * n + i] = G;
       gd = fmaf(G, dc, gd);
     }
   }
@@ -1467,16 +1494,17 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
     const int m = ((int)blockIdx.x - 1) * LF_WAVES + wid;
     if (m >= p.S * p.B) return;
     const int s = m / p.B, b = m - s * p.B;
-    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
+    const int nblk = sel(p.L.nblk, s);
+    const long base = (long)sel(p.L.blk_off, s) + (long)b * nblk;
     float a0 = 0.f, a1 = 0.f;
-    for (int k = lane; k < p.L.nblk[s]; k += kWave) {
+    for (int k = lane; k < nblk; k += kWave) {
       a0 += p.sm_part[(base + k) * 4 + 3];
       a1 += p.sm_part[(base + k) * 4 + 2];
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
     if (lane == kSumLane) {
-      p.img_scal[2 * m + 0] = a0 / (float)((long)p.L.Hs[s] * p.L.Ws[s]);
+      p.img_scal[2 * m + 0] = a0 / (float)((long)(p.H >> s) * (p.W >> s));
       p.img_scal[2 * m + 1] = a1;
     }
     return;
@@ -1495,26 +1523,60 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
     acc[9] += (double)v.w;
   }
   // smoothness: the sums of an image times 1 / (its mean disparity + 1e-7); one
-  // image per wave and pass, lane kSumLane of the wave keeps the running sums
-  for (int m = wid; m < p.S * p.B; m += LF_WAVES) {
-    const int s = m / p.B, b = m - s * p.B;
-    const long base = (long)p.L.blk_off[s] + (long)b * p.L.nblk[s];
-    float ax = 0.f, ay = 0.f, ad = 0.f;
-    for (int k = lane; k < p.L.nblk[s]; k += kWave) {
-      const float4 v = *reinterpret_cast<const float4*>(p.sm_part + (base + k) * 4);
-      ax += v.x;
-      ay += v.y;
-      ad += v.w;
-    }
-    ax = wave_sum(ax);
-    ay = wave_sum(ay);
-    ad = wave_sum(ad);
-    const float mean = ad / (float)((long)p.L.Hs[s] * p.L.Ws[s]);
-    const double inv = (double)(1.0f / (mean + kMeanEps));
+  // image per wave and pass, lane kSumLane of the wave keeps the running sums.  The kernel is a
+  // chain of load latencies: a wave takes LF_U images at a time and has the first two partials a
+  // lane needs of each of them in flight together (an image of up to 128 blocks -- 192 x 640 --
+  // needs no more), before it sums any.
+  constexpr int LF_U = 4;
+  for (int m0 = wid; m0 < p.S * p.B; m0 += LF_WAVES * LF_U) {
+    float4 pre[LF_U][2];
+    int sc[LF_U], nb[LF_U];
+    long base[LF_U];
 #pragma unroll
-    for (int j = 0; j < DW_MAX_SCALES; ++j) {
-      acc[3 * j + 1] += (s == j) ? inv * (double)ax : 0.0;
-      acc[3 * j + 2] += (s == j) ? inv * (double)ay : 0.0;
+    for (int u = 0; u < LF_U; ++u) {
+      const int m = m0 + u * LF_WAVES;
+      const bool on = m < p.S * p.B;
+      const int s = on ? m / p.B : 0, b = on ? m - s * p.B : 0;
+      sc[u] = on ? s : -1;
+      nb[u] = on ? sel(p.L.nblk, s) : 0;
+      base[u] = (long)sel(p.L.blk_off, s) + (long)b * nb[u];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = lane + h * kWave;
+        pre[u][h] = (k < nb[u]) ? *reinterpret_cast<const float4*>(p.sm_part + (base[u] + k) * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LF_U; ++u) {
+      if (sc[u] < 0) continue;  // uniform over the wave
+      const int s = sc[u];
+      // the order of the additions is that of a plain loop over k = lane, lane + 64, ...
+      float ax = 0.f, ay = 0.f, ad = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (lane + h * kWave < nb[u]) {
+          ax += pre[u][h].x;
+          ay += pre[u][h].y;
+          ad += pre[u][h].w;
+        }
+      }
+      for (int k = lane + 2 * kWave; k < nb[u]; k += kWave) {
+        const float4 v = *reinterpret_cast<const float4*>(p.sm_part + (base[u] + k) * 4);
+        ax += v.x;
+        ay += v.y;
+        ad += v.w;
+      }
+      ax = wave_sum(ax);
+      ay = wave_sum(ay);
+      ad = wave_sum(ad);
+      const float mean = ad / (float)((long)(p.H >> s) * (p.W >> s));
+      const double inv = (double)(1.0f / (mean + kMeanEps));
+#pragma unroll
+      for (int j = 0; j < DW_MAX_SCALES; ++j) {
+        acc[3 * j + 1] += (s == j) ? inv * (double)ax : 0.0;
+        acc[3 * j + 2] += (s == j) ? inv * (double)ay : 0.0;
+      }
     }
   }
   // (only lane kSumLane holds wave sums: the other lanes' smoothness sums are discarded below)
@@ -1539,7 +1601,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p
   if (tid == 0) {
     double total = 0.0;
     for (int s = 0; s < p.S; ++s) {
-      const int hs = p.L.Hs[s], ws = p.L.Ws[s];
+      const int hs = p.H >> s, ws = p.W >> s;
       const double photo = s_part[3 * s][0] / ((double)p.B * p.H * p.W);
       const double sm = s_part[3 * s + 1][0] / ((double)p.B * hs * (ws - 1)) +
                         s_part[3 * s + 2][0] / ((double)p.B * (hs - 1) * ws);
@@ -1559,6 +1621,7 @@ struct BwdParams {
   const float* K;
   const float* grad_loss;  // upstream gradient of loss_out: [0] the total; with g_len = 1 + 2S also
   int g_len;               // [1 + s] of L_photo[s] and [1 + S + s] of L_sm[s]
+  int vec4;                // full resolution: H * W is a multiple of 4 and grad_disp[0] is 16-byte aligned
   const float* tile_dP;
   const float* gdup;
   const float* img_scal;
@@ -1575,18 +1638,79 @@ struct BwdParams {
   ScaleLayout L;
 };
 
+struct GatherArgs {
+  const float* gup;
+  const float* G;
+  float* out;
+  long n;
+  int chunk, ppb, hs, ws, H, W;
+  float coef, inv, mean_term, g0;
+};
+
+// Adjoint of the bilinear up-sampling for scale S_ >= 1 as a gather from the full-resolution
+// gradient map: a coarse pixel receives from a window of 2 * 2^S_ rows and columns.  The kernel is
+// bound by the number of load instructions (a partly filled 64-lane gather costs the address unit
+// the same as a full one), so a lane takes four neighbouring columns as one 16-byte load (dword
+// aligned) and walks down the rows; the 2^S_ / 2 lanes of a pixel are summed with DPP, fixed order.
+template <int S_>
+__device__ __forceinline__ void gather_upsampling_adjoint(const GatherArgs& a) {
+  static_assert(S_ >= 1 && S_ <= 3, "window of at most 16 columns: four lanes of a quad");
+  constexpr int K2 = 1 << S_;
+  constexpr int LP_SHIFT = S_ - 1;  // lanes per pixel = 2 * 2^s / 4
+  const int r = threadIdx.x & ((1 << LP_SHIFT) - 1);
+  const float sy = (float)a.hs / (float)a.H, sx = (float)a.ws / (float)a.W;
+#pragma unroll 1
+  for (int pass = 0; pass < GD_PASSES; ++pass) {
+    const int pix = pass * (SM_NT >> LP_SHIFT) + (threadIdx.x >> LP_SHIFT);
+    const long i = (long)a.chunk * a.ppb + pix;
+    const bool act = i < a.n;
+    const long ic = act ? i : 0;
+    // 32-bit index arithmetic (n < 2^30)
+    const int y = (int)((unsigned)ic / (unsigned)a.ws), x = (int)((unsigned)ic - (unsigned)y * (unsigned)a.ws);
+    // full-resolution rows / columns with a bilinear tap at (y, x)
+    const int Ya = max(0, (y - 1) * K2 + K2 / 2), Yb = min(a.H - 1, (y + 1) * K2 + K2 / 2 - 1);
+    const int Xa = max(0, (x - 1) * K2 + K2 / 2), Xb = min(a.W - 1, (x + 1) * K2 + K2 / 2 - 1);
+    // lane r answers for the columns Xa + 4r .. Xa + 4r + 3 (up to Xb); its load starts there,
+    // or further left where that keeps the four columns inside the row (W >= 4 at these scales'
+    // full resolution: W is a multiple of 8); a column it holds but does not answer for gets
+    // weight 0
+    const int X0 = Xa + 4 * r, Xs = min(X0, a.W - 4);
+    float wc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int X = Xs + e;
+      wc[e] = (X >= X0 && X <= Xb) ? upsample_weight(X, x, a.ws, sx) : 0.f;
+    }
+    float acc = 0.f;
+    if (act && X0 <= Xb) {
+      const float* col = a.gup + Xs;
+#pragma unroll 4
+      for (int Y = Ya; Y <= Yb; ++Y) {
+        const QuadU q = *reinterpret_cast<const QuadU*>(col + (long)Y * a.W);
+        const float rowsum = fmaf(wc[3], q.w, fmaf(wc[2], q.z, fmaf(wc[1], q.y, wc[0] * q.x)));
+        acc = fmaf(upsample_weight(Y, y, a.hs, sy), rowsum, acc);
+      }
+    }
+    if (S_ >= 2) acc = dpp_add<0xb1, 0xf>(acc);   // quad_perm:[1,0,3,2]: two lanes
+    if (S_ >= 3) acc = dpp_add<0x4e, 0xf>(acc);   // quad_perm:[2,3,0,1]: four lanes
+    if (act && r == 0) a.out[i] = a.coef * (a.G[i] * a.inv - a.mean_term) + a.g0 * acc;
+  }
+}
+
 __device__ __forceinline__ void grad_disp_block(const BwdParams& p, int blk) {
   // Full resolution is a plain map (1024 pixels per block, four per thread).  A
   // coarser scale s gathers the adjoint of the bilinear up-sampling from the
   // full-resolution gradient map: a pixel receives from 2 * 2^s columns, one lane
   // per column, summed over the lanes with DPP (fixed order).
   int k = 0;
-  while (k + 1 < p.S && blk >= p.g_off[k + 1]) ++k;
+#pragma unroll
+  for (int j = 1; j < DW_MAX_SCALES; ++j) k += (j < p.S && blk >= p.g_off[j]) ? 1 : 0;  // g_off ascends
   const int s = p.S - 1 - k;
-  const int rblk = blk - p.g_off[k];
-  const int b = rblk / p.g_nblk[s], chunk = rblk - b * p.g_nblk[s];
-  const int ppb = p.g_ppb[s];
-  const int hs = p.L.Hs[s], ws = p.L.Ws[s];
+  const int rblk = blk - sel(p.g_off, k);
+  const int nblk_s = sel(p.g_nblk, s);
+  const int b = rblk / nblk_s, chunk = rblk - b * nblk_s;
+  const int ppb = sel(p.g_ppb, s);
+  const int hs = p.H >> s, ws = p.W >> s;
   const long n = (long)hs * ws;
   const int H = p.H, W = p.W;
   const long plane = (long)H * W;
@@ -1601,10 +1725,23 @@ __device__ __forceinline__ void grad_disp_block(const BwdParams& p, int blk) {
     g0 = (go / (float)p.S + p.grad_loss[1 + s]) / ((float)p.B * (float)plane);
   }
   const float mean_term = sum_gd * inv * inv / (float)n;
-  const float* G = p.sm_G + p.L.pix_off[s] + (long)b * n;
+  const float* G = p.sm_G + sel(p.L.pix_off, s) + (long)b * n;
   const float* gup = p.gdup + ((long)s * p.B + b) * plane;
-  float* out = p.grad_disp[s] + (long)b * n;
+  float* out = sel(p.grad_disp, s) + (long)b * n;
   if (s == 0) {
+    if (p.vec4) {  // whole 16-byte groups: four pixels per thread, one load and one store each
+      const long i = (long)chunk * ppb + 4 * threadIdx.x;
+      if (i < n) {
+        const float4 g = *reinterpret_cast<const float4*>(G + i), u = *reinterpret_cast<const float4*>(gup + i);
+        float4 o;
+        o.x = coef * (g.x * inv - mean_term) + g0 * u.x;
+        o.y = coef * (g.y * inv - mean_term) + g0 * u.y;
+        o.z = coef * (g.z * inv - mean_term) + g0 * u.z;
+        o.w = coef * (g.w * inv - mean_term) + g0 * u.w;
+        *reinterpret_cast<float4*>(out + i) = o;
+      }
+      return;
+    }
     for (int k = threadIdx.x; k < ppb; k += SM_NT) {
       const long i = (long)chunk * ppb + k;
       if (i >= n) break;
@@ -1612,36 +1749,13 @@ __device__ __forceinline__ void grad_disp_block(const BwdParams& p, int blk) {
     }
     return;
   }
-  const int k2 = 1 << s;
-  const int lp_shift = s + 1;  // lanes per pixel = 2 * 2^s <= 16: groups never straddle a DPP row
-  const int r = threadIdx.x & ((1 << lp_shift) - 1);
-  const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
-  // GD_PASSES pixels per lane group, one after the other (fewer, longer blocks)
-  for (int pass = 0; pass < GD_PASSES; ++pass) {
-    const int pix = pass * (SM_NT >> lp_shift) + (threadIdx.x >> lp_shift);
-    const long i = (long)chunk * ppb + pix;
-    const bool act = i < n;
-    const long ic = act ? i : 0;
-    // 32-bit index arithmetic (n < 2^30)
-    const int y = (int)((unsigned)ic / (unsigned)ws), x = (int)((unsigned)ic - (unsigned)y * (unsigned)ws);
-    // full-resolution rows / columns with a bilinear tap at (y, x)
-    const int Ya = max(0, (y - 1) * k2 + k2 / 2), Yb = min(H - 1, (y + 1) * k2 + k2 / 2 - 1);
-    const int Xa = max(0, (x - 1) * k2 + k2 / 2), Xb = min(W - 1, (x + 1) * k2 + k2 / 2 - 1);
-    // lane r takes column Xa + r and walks down the rows: the lanes of a pixel, and
-    // of its neighbours in the wave, read one contiguous run per row
-    const int X = Xa + r;
-    float acc = 0.f;
-    if (act && X <= Xb) {
-      const float* col = gup + X;
-#pragma unroll 4
-      for (int Y = Ya; Y <= Yb; ++Y) acc = fmaf(upsample_weight(Y, y, hs, sy), col[(long)Y * W], acc);
-      acc *= upsample_weight(X, x, ws, sx);
-    }
-    acc = dpp_add<0xb1, 0xf>(acc);                // quad_perm:[1,0,3,2]
-    acc = dpp_add<0x4e, 0xf>(acc);                // quad_perm:[2,3,0,1]
-    if (s >= 2) acc = dpp_add<0x141, 0xf>(acc);   // row_half_mirror: 8 lanes
-    if (s >= 3) acc = dpp_add<0x140, 0xf>(acc);   // row_mirror: 16 lanes
-    if (act && r == 0) out[i] = coef * (G[i] * inv - mean_term) + g0 * acc;
+  // the scale as a compile-time constant: the row loop of a lane is then a fixed number of loads,
+  // all of them issued before the first is used
+  const GatherArgs ga{gup, G, out, n, chunk, ppb, hs, ws, H, W, coef, inv, mean_term, g0};
+  switch (s) {
+    case 1: gather_upsampling_adjoint<1>(ga); break;
+    case 2: gather_upsampling_adjoint<2>(ga); break;
+    default: gather_upsampling_adjoint<3>(ga); break;
   }
 }
 
@@ -2191,6 +2305,8 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   p.K = K;
   p.grad_loss = grad_loss;
   p.g_len = grad_loss_len;
+  static_assert(SM_PX == 4 * SM_NT, "four pixels per thread in the full-resolution blocks");
+  p.vec4 = (((long)desc->H * desc->W) % 4 == 0 && ((uintptr_t)grad_disp[0] & 15) == 0) ? 1 : 0;
   const char* ws = (const char*)workspace;
   p.tile_dP = (const float*)(ws + w.tile_dP);
   p.gdup = (const float*)(ws + w.gdup);
@@ -2201,7 +2317,7 @@ extern "C" int dw_photometric_bwd(const dw_desc* desc, const float* const* disp,
   hipStream_t st = (hipStream_t)stream;
   p.g_off[0] = 0;
   for (int s = 0; s < DW_MAX_SCALES; ++s) {
-    p.g_ppb[s] = (s == 0) ? SM_PX : GD_PASSES * (SM_NT / (2 << s));  // coarse scales: 2 * 2^s lanes per pixel
+    p.g_ppb[s] = (s == 0) ? SM_PX : GD_PASSES * (SM_NT / ((2 << s) / 4));  // coarse scales: 2 * 2^s / 4 lanes per pixel
     p.g_nblk[s] = (s < p.S) ? (p.L.Hs[s] * p.L.Ws[s] + p.g_ppb[s] - 1) / p.g_ppb[s] : 0;
   }
   for (int k = 0; k < DW_MAX_SCALES; ++k)
