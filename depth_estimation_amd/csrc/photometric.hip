@@ -423,7 +423,9 @@ constexpr int DU_NT = 256;
 // thread are loaded before the first is used.  `blk`: block of sample `b`.
 // (Reading the taps of the four pixels as one dword-aligned 16-byte load per tap row and picking
 // them out of it -- 7 loads per thread instead of 52 -- is slower: 28 against 21 us for the
-// launch; the lanes' 16-byte windows overlap and are not aligned.)
+// launch; the lanes' 16-byte windows overlap and are not aligned.  Nor do 8 x 128 tiles whose three
+// coarse rectangles are copied to LDS with row-contiguous loads, three per thread: 21.2 us.  The
+// launch moves 70 MB in 21 us and is at what a launch this short gets out of the memory system.)
 template <int PX>
 __device__ __forceinline__ void depth_up_block(const PhotoParams& p, int b, int blk) {
   const int H = p.H, W = p.W;
