@@ -255,7 +255,7 @@ def sweep_case(seed, B, H, W):
 
 
 def test_parity_sweep_outlier_ill_conditioned_pose():
-    """The one case in 300 of the seed sweep (`profiles/r02_parity_sweep.json`) whose disparity
+    """The one case in 300 of the seed sweep (`tools/parity_sweep.py`) whose disparity
     gradient differs from the float32 oracle by more than 1e-4 (2.1e-4 at one coarse-scale pixel).
     Its pose makes the projection adjoint cancel: the float32 oracle itself is up to 1.6e-2 away
     from the same oracle evaluated in float64.  Checked here against the float64 evaluation: the
