@@ -117,6 +117,7 @@ struct PhotoParams {
   int B, H, W, S;
   int tilesX, tilesY;  // of the kernel being launched
   int n_full;          // blocks [0, n_full) run every scale of one tile; the rest one scale each
+  int n_tile_blocks;   // blocks of the tile launch that work on tiles; those behind them sum up the images' smoothness partials
   int vec4;            // every scale's width is a multiple of 4 and every map pointer 16-byte aligned
   int du_px, du_nblk;  // depth maps: pixels per thread (4 or 1) and blocks per sample
   // (H >> s) / H and (W >> s) / W as the float32 quotients the up-sampling formula uses: the same
@@ -137,6 +138,7 @@ struct PhotoParams {
   float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
   float* gxout;      // [S][B][2][3][H][W]      d loss / d (warped colour of frame f), unit upstream; optional
   float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
+  double* sm_img;    // [S][B][2]               per image: its smoothness sums x, y times 1 / (mean disparity + 1e-7)
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
   float* sm_part;    // [blk_off[S]][4]         per block: smoothness sums x, y; sum G * disp; sum disp
   ScaleLayout L;
@@ -1307,11 +1309,56 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
 #endif
 }
 
+// The blocks behind the tile blocks of a tile launch, one image (scale, sample) per wave: the
+// image's smoothness partials (left by the smoothness kernel, the launch before) summed up --
+// mean disparity, sum of G * disp for the backward pass, and the two smoothness sums scaled by
+// 1 / (mean + 1e-7) for the loss.  These few short chains of dependent loads used to be the
+// larger part of the loss kernel that follows the tiles; here they run in slots the last,
+// partial round of tiles leaves free.
+template <int NT>
+__device__ __forceinline__ void image_sums_block(const PhotoParams& p, int k) {
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int m = k * (NT / kWave) + wid;
+  if (m >= p.S * p.B) return;
+  const int s = m / p.B, b = m - s * p.B;
+  const int nblk = sel(p.L.nblk, s);
+  const long base = (long)sel(p.L.blk_off, s) + (long)b * nblk;
+  float ax = 0.f, ay = 0.f, ag = 0.f, ad = 0.f;
+#pragma unroll 2
+  for (int j = lane; j < nblk; j += kWave) {
+    const float4 v = *reinterpret_cast<const float4*>(p.sm_part + (base + j) * 4);
+    ax += v.x;
+    ay += v.y;
+    ag += v.z;
+    ad += v.w;
+  }
+  ax = wave_sum(ax);
+  ay = wave_sum(ay);
+  ag = wave_sum(ag);
+  ad = wave_sum(ad);
+  if (lane == kSumLane) {
+    const float mean = ad / (float)((long)(p.H >> s) * (p.W >> s));
+    const double inv = (double)(1.0f / (mean + kMeanEps));
+    p.img_scal[2 * m + 0] = mean;
+    p.img_scal[2 * m + 1] = ag;
+    p.sm_img[2 * m + 0] = inv * (double)ax;
+    p.sm_img[2 * m + 1] = inv * (double)ay;
+  }
+}
+
 template <bool GRAD>
 __global__ __launch_bounds__(Geom<GRAD>::NT, Geom<GRAD>::MINW) void photo_tile_kernel(const PhotoParams p) {
+  if ((int)blockIdx.x >= p.n_tile_blocks) {
+    image_sums_block<Geom<GRAD>::NT>(p, (int)blockIdx.x - p.n_tile_blocks);
+    return;
+  }
   photo_tile_body<GRAD, false>(p);
 }
 __global__ __launch_bounds__(Geom<true>::NT, Geom<true>::MINW) void photo_tile_color_kernel(const PhotoParams p) {
+  if ((int)blockIdx.x >= p.n_tile_blocks) {
+    image_sums_block<Geom<true>::NT>(p, (int)blockIdx.x - p.n_tile_blocks);
+    return;
+  }
   photo_tile_body<true, true>(p);
 }
 
@@ -1481,123 +1528,48 @@ __global__ __launch_bounds__(SM_NT) void smooth_kernel(const PhotoParams p) {
 }
 
 // ------------------------------------------------- scalar loss
-// Blocks of 1024 threads.  Block 0: all 3*S sums (tile losses, smoothness x, y)
-// are accumulated in double in one pass over the partials (the S tile partials
-// of a tile are one 16-byte load), reduced per wave with shuffles and across
-// waves by one thread: fixed order.  Blocks 1..: the per-image scalars of the
-// backward pass, one image per wave.
+// One block of 1024 threads: the S tile-loss sums are accumulated in double in one pass over the
+// partials (the S partials of a tile are one 16-byte load), reduced per wave with shuffles and
+// across waves by one thread; the smoothness sums of the images (left by the blocks behind the
+// tiles) are added per scale in sample order.  Fixed order throughout.
 constexpr int LF_WAVES = 1024 / kWave;
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const PhotoParams p, float* loss_out) {
   __shared__ double s_part[3 * DW_MAX_SCALES][LF_WAVES];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
-  if (blockIdx.x > 0) {
-    // per image (scale, sample): mean of disp and sum of G * disp, from the per-block
-    // partials; read by the backward kernel, which then needs no reduction of its own
-    const int m = ((int)blockIdx.x - 1) * LF_WAVES + wid;
-    if (m >= p.S * p.B) return;
-    const int s = m / p.B, b = m - s * p.B;
-    const int nblk = sel(p.L.nblk, s);
-    const long base = (long)sel(p.L.blk_off, s) + (long)b * nblk;
-    float a0 = 0.f, a1 = 0.f;
-    for (int k = lane; k < nblk; k += kWave) {
-      a0 += p.sm_part[(base + k) * 4 + 3];
-      a1 += p.sm_part[(base + k) * 4 + 2];
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == kSumLane) {
-      p.img_scal[2 * m + 0] = a0 / (float)((long)(p.H >> s) * (p.W >> s));
-      p.img_scal[2 * m + 1] = a1;
-    }
-    return;
-  }
   const int ntile = p.B * p.tilesX * p.tilesY;
-  double acc[3 * DW_MAX_SCALES];
+  double acc[DW_MAX_SCALES];
 #pragma unroll
-  for (int k = 0; k < 3 * DW_MAX_SCALES; ++k) acc[k] = 0.0;
+  for (int k = 0; k < DW_MAX_SCALES; ++k) acc[k] = 0.0;
   const float4* tl = reinterpret_cast<const float4*>(p.tile_loss);
 #pragma unroll 4
   for (int t = tid; t < ntile; t += 1024) {
     const float4 v = tl[t];
     acc[0] += (double)v.x;
-    acc[3] += (double)v.y;
-    acc[6] += (double)v.z;
-    acc[9] += (double)v.w;
+    acc[1] += (double)v.y;
+    acc[2] += (double)v.z;
+    acc[3] += (double)v.w;
   }
-  // smoothness: the sums of an image times 1 / (its mean disparity + 1e-7); one
-  // image per wave and pass, lane kSumLane of the wave keeps the running sums.  The kernel is a
-  // chain of load latencies: a wave takes LF_U images at a time and has the first two partials a
-  // lane needs of each of them in flight together (an image of up to 128 blocks -- 192 x 640 --
-  // needs no more), before it sums any.
-  constexpr int LF_U = 4;
-  for (int m0 = wid; m0 < p.S * p.B; m0 += LF_WAVES * LF_U) {
-    float4 pre[LF_U][2];
-    int sc[LF_U], nb[LF_U];
-    long base[LF_U];
 #pragma unroll
-    for (int u = 0; u < LF_U; ++u) {
-      const int m = m0 + u * LF_WAVES;
-      const bool on = m < p.S * p.B;
-      const int s = on ? m / p.B : 0, b = on ? m - s * p.B : 0;
-      sc[u] = on ? s : -1;
-      nb[u] = on ? sel(p.L.nblk, s) : 0;
-      base[u] = (long)sel(p.L.blk_off, s) + (long)b * nb[u];
+  for (int k = 0; k < DW_MAX_SCALES; ++k) {
+    double a = acc[k];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = lane + h * kWave;
-        pre[u][h] = (k < nb[u]) ? *reinterpret_cast<const float4*>(p.sm_part + (base[u] + k) * 4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < LF_U; ++u) {
-      if (sc[u] < 0) continue;  // uniform over the wave
-      const int s = sc[u];
-      // the order of the additions is that of a plain loop over k = lane, lane + 64, ...
-      float ax = 0.f, ay = 0.f, ad = 0.f;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (lane + h * kWave < nb[u]) {
-          ax += pre[u][h].x;
-          ay += pre[u][h].y;
-          ad += pre[u][h].w;
-        }
-      }
-      for (int k = lane + 2 * kWave; k < nb[u]; k += kWave) {
-        const float4 v = *reinterpret_cast<const float4*>(p.sm_part + (base[u] + k) * 4);
-        ax += v.x;
-        ay += v.y;
-        ad += v.w;
-      }
-      ax = wave_sum(ax);
-      ay = wave_sum(ay);
-      ad = wave_sum(ad);
-      const float mean = ad / (float)((long)(p.H >> s) * (p.W >> s));
-      const double inv = (double)(1.0f / (mean + kMeanEps));
-#pragma unroll
-      for (int j = 0; j < DW_MAX_SCALES; ++j) {
-        acc[3 * j + 1] += (s == j) ? inv * (double)ax : 0.0;
-        acc[3 * j + 2] += (s == j) ? inv * (double)ay : 0.0;
-      }
-    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+    if (lane == 0) s_part[3 * k][wid] = a;
   }
-  // (only lane kSumLane holds wave sums: the other lanes' smoothness sums are discarded below)
+  if (wid < 2 * DW_MAX_SCALES) {  // wave 2 s + c: smoothness sum c (x, y) of scale s over the samples
+    const int sc = wid >> 1, c = wid & 1;
+    double a = 0.0;
+    if (sc < p.S)
+      for (int b = lane; b < p.B; b += kWave) a += p.sm_img[2 * (sc * p.B + b) + c];
 #pragma unroll
-  for (int k = 0; k < 3 * DW_MAX_SCALES; ++k) {
-    if (k % 3 == 0) {  // tile losses: every lane has a partial sum
-      double a = acc[k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
-      if (lane == 0) s_part[k][wid] = a;
-    } else if (lane == kSumLane) {
-      s_part[k][wid] = acc[k];
-    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, kWave);
+    if (lane == 0) s_part[3 * sc + 1 + c][0] = a;
   }
   __syncthreads();
-  if (tid < 3 * DW_MAX_SCALES) {  // thread k finishes sum k
+  if (tid < DW_MAX_SCALES) {  // thread k finishes the tile-loss sum of scale k
     double a = 0.0;
-    for (int w = 0; w < LF_WAVES; ++w) a += s_part[tid][w];
-    s_part[tid][0] = a;
+    for (int w = 0; w < LF_WAVES; ++w) a += s_part[3 * tid][w];
+    s_part[3 * tid][0] = a;
   }
   __syncthreads();
   if (tid == 0) {
@@ -2054,7 +2026,7 @@ __global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, 
 
 // ------------------------------------------------------------- host side
 struct WsLayout {
-  size_t tile_loss, tile_dP, depth_up, gdup, img_scal, sm_G, sm_part, total;
+  size_t tile_loss, tile_dP, depth_up, gdup, img_scal, sm_img, sm_G, sm_part, total;
   // only with DW_FLAG_COLOR_GRAD: [color_zero_begin, color_zero_end) is cleared by every forward call
   size_t gxout, slots, anchors, spill_flag, gcol, color_zero_begin, color_zero_end;
   int cX, cY;  // tiles of the colour scatter
@@ -2098,6 +2070,8 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   o = align_up(o + sizeof(float) * (size_t)L.pix_off[d.S], A);
   w.img_scal = o;
   o = align_up(o + sizeof(float) * (size_t)DW_MAX_SCALES * d.B * 2, A);
+  w.sm_img = o;
+  o = align_up(o + sizeof(double) * (size_t)DW_MAX_SCALES * d.B * 2, A);
   w.depth_up = o;
   o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
   w.gdup = o;  // last section (the diagnostic stamps overwrite its start)
@@ -2223,6 +2197,7 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   p.gdup = (float*)(ws + w.gdup);
   p.depth_up = (float*)(ws + w.depth_up);
   p.img_scal = (float*)(ws + w.img_scal);
+  p.sm_img = (double*)(ws + w.sm_img);
   p.sm_G = (float*)(ws + w.sm_G);
   p.sm_part = (float*)(ws + w.sm_part);
   hipStream_t st = (hipStream_t)stream;
@@ -2246,7 +2221,10 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
 
   const int n_tiles = p.tilesX * p.tilesY * p.B;
   p.n_full = full_blocks(n_tiles, p.S, desc->flags, with_grad ? Geom<true>::PER_CU : Geom<false>::PER_CU);
-  const dim3 tgrid(p.n_full + (n_tiles - p.n_full) * p.S);
+  p.n_tile_blocks = p.n_full + (n_tiles - p.n_full) * p.S;
+  // behind the tile blocks: one wave per image (scale, sample) for the images' smoothness sums
+  const int waves_per_block = (with_grad ? Geom<true>::NT : Geom<false>::NT) / kWave;
+  const dim3 tgrid(p.n_tile_blocks + (p.S * p.B + waves_per_block - 1) / waves_per_block);
   // depth maps: four pixels per thread when rows are whole 16-byte groups (every plane of the
   // workspace section is 256-byte aligned then)
   p.du_px = (p.W & 3) ? 1 : 4;
@@ -2274,8 +2252,7 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
     smooth_kernel<false><<<map_blocks, SM_NT, 0, st>>>(p);
     photo_tile_kernel<false><<<tgrid, Geom<false>::NT, 0, st>>>(p);
   }
-  // without gradients nobody reads the per-image scalars: block 0 alone
-  loss_finalize_kernel<<<with_grad ? 1 + (p.S * p.B + LF_WAVES - 1) / LF_WAVES : 1, 1024, 0, st>>>(p, loss_out);
+  loss_finalize_kernel<<<1, 1024, 0, st>>>(p, loss_out);
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
 
