@@ -72,3 +72,19 @@ def test_lidar_oracle_forms_agree():
     assert len(pts) > 200 and (depth > 0).sum() > 100
     # every kept point is inside the image and in front of the sensor
     assert pts[:, 0].min() >= 0 and pts[:, 0].max() < shape[1] and pts[:, 1].max() < shape[0]
+
+
+def test_oracles_reproduce_the_committed_vectors():
+    """`tests/golden/next_rows.npz` (written by tests/golden/make_golden.py from these oracles on
+    seeded inputs): a change to a restatement that alters its results shows up here."""
+    import os
+    import numpy as np
+    from tests.golden.make_golden import next_inputs, next_outputs
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "next_rows.npz"))
+    got = next_outputs(next_inputs())
+    assert sorted(gold.files) == sorted(got)
+    for k in ("cost_left", "cost_right", "lidar_pts", "lidar_depth"):   # copies and float64 selection: exact
+        assert np.array_equal(got[k], gold[k]), k
+    for k in ("soft_argmin", "soft_argmin_grad", "rmse", "normalized"):
+        assert np.allclose(got[k], gold[k], rtol=1e-6, atol=1e-7), k
+    assert (gold["lidar_depth"] > 0).sum() > 100 and gold["lidar_pts"].shape[0] > 200
