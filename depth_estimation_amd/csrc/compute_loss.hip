@@ -23,9 +23,17 @@
 //   min(pred), max(pred) for normalize_image                     train.py:248-253
 // and normalize_image itself is the element-wise kernel at the end of the file.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "dw_common.h"
+
+// Measurement builds only (tools/build_variant.sh compute_loss NAME -DDW_TUNING -DDW_CL_KO=n): 1 leaves the
+// row loads out of the walk (the first row is worked on again and again), 2 leaves the filters, the SSIM
+// and the Sobel sums out (loads, row exchange and the absolute difference stay).  0 in the product.
+#ifndef DW_CL_KO
+#define DW_CL_KO 0
+#endif
 
 namespace dw {
 
@@ -279,7 +287,9 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
         st[hc] = resized(row, 2);
         sq[hc] = row.qh;
       }
+#if DW_CL_KO != 1
       if (r < r_last) row = fetch(r + 1);  // in flight while this row is worked on
+#endif
       __syncthreads();
       float a[8], q[8];
 #pragma unroll
@@ -291,6 +301,7 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
         q[2 * k] = vq.x;
         q[2 * k + 1] = vq.y;
       }
+#if DW_CL_KO != 2
       float e[8], c[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
         win[ph][4][j] = tr - tl;
         win[ph][5][j] = (tl + 2.f * tc) + tr;
       }
+#endif
       if (r >= y0 && r < y1) {  // absolute difference (and the metrics) of this row
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -325,6 +337,7 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
           }
         }
       }
+#if DW_CL_KO != 2
       const int ys = r - 1;  // Sobel of the row above this one, replicate border in y
       if (ys >= y0 && ys < y1) {
         const int UP = (ph + 5) % 7, MID = (ph + 6) % 7, DN = ph;  // constants once unrolled
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(CL_NT) void compute_loss_strip_kernel(const ClParam
           sss[j] += fminf(fmaxf((1.f - ssim) * 0.5f, 0.f), 1.f);
         }
       }
+#endif
       ++r;
     }
   }
@@ -586,7 +600,11 @@ using namespace dw;
 // Rows per chunk: as tall as leaves about `kWantWaves` waves for the launch (a strip re-filters six
 // halo rows per chunk, so taller is cheaper as long as the chip stays full).
 static int compute_loss_rows(int B, int H, int W) {
+#ifdef DW_TUNING  // tools/cl_sweep.sh: the launch size from the environment
+  const long kWantWaves = getenv("DW_CL_WAVES") ? atol(getenv("DW_CL_WAVES")) : 3072;
+#else
   constexpr long kWantWaves = 3072;  // three per SIMD; measured flat between two and four
+#endif
   const long strips = (W + CL_CW - 1) / CL_CW;
   const long want_chunks = std::max<long>(1, kWantWaves / (strips * B));
   const long rows = (H + want_chunks - 1) / want_chunks;

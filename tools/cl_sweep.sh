@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/cl_sweep.sh LIB WAVES... -- compute_loss bench lines for several launch sizes
+# usage (GPU box): tools/cl_sweep.sh LIB WAVES... -- compute_loss bench lines for several launch sizes (LIB built with -DDW_TUNING)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 LIB=$1; shift
 for w in "$@"; do
