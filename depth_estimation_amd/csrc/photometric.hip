@@ -137,6 +137,7 @@ struct PhotoParams {
   float* depth_up;   // [S][B][H][W]            depth from the up-sampled disparity of every scale
   float* gdup;       // [S][B][H][W]            d loss / d (up-sampled disp[s]), photometric part
   float* gxout;      // [S][B][2][3][H][W]      d loss / d (warped colour of frame f), unit upstream; optional
+  unsigned char* gany;  // [S][B][H][W]          bit f: frame f won somewhere in the pixel's 3 x 3 window
   float* img_scal;   // [S][B][2]               per image: mean of disp[s], sum of G * disp[s]
   double* sm_img;    // [S][B][2]               per image: its smoothness sums x, y times 1 / (mean disparity + 1e-7)
   float* sm_G;       // concatenated per scale [B][Hs][Ws]
@@ -1079,6 +1080,17 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
         bool wave_live = false;
 #pragma unroll
         for (int q = 0; q < SW; ++q) wave_live = wave_live || live[q];
+        if (CGRAD) {
+          // which frames' warped colours carry a gradient at this pixel: the scatter kernel finds its
+          // work in these bytes (12 MB) instead of scanning the adjoint planes (141 MB)
+#pragma unroll
+          for (int q = 0; q < SW; ++q) {
+            const int x = sx_img + q, qc = SW * ql + q;
+            if (qc >= CO && qc < QW - CO && x < W)
+              p.gany[((long)s * p.B + b) * plane + (long)sy_img * W + x] =
+                  (unsigned char)((any[0][q] ? 1 : 0) | (any[1][q] ? 2 : 0));
+          }
+        }
         if (CGRAD || __builtin_amdgcn_ballot_w64(wave_live) != 0ull) {
         // Window-sum adjoint, one colour channel (three coefficient planes) at a
         // time and both frames in the same pass over LDS: `tot` is the sum over
@@ -1175,6 +1187,8 @@ __device__ __forceinline__ void photo_tile_body(const PhotoParams& p) {
               if (CGRAD) {
                 // adjoint of the warped colour itself, for the scatter to the source image
                 const int x = sx_img + q, qc = SW * ql + q;
+                // (stored for every pixel, zeros included: whole cache lines are cheaper to write than
+                // the lanes with a gradient alone, 309 against 345 us for the launch)
                 if (qc >= CO && qc < QW - CO && x < W)
                   p.gxout[((((long)s * p.B + b) * 2 + f) * 3 + c) * plane + (long)sy_img * W + x] =
                       (live[q] && any[f][q]) ? gx : 0.f;
@@ -1803,9 +1817,9 @@ __global__ __launch_bounds__(SM_NT) void backward_kernel(const BwdParams p) {
 // is anchored where the tile's centre pixel samples the frame (scale 0), so for
 // ordinary motion every tap of the tile falls inside it; the sums are 64-bit
 // fixed point (2^-32 units), which makes them independent of the order in which
-// the lanes arrive.  The patch then goes to a slot of its own in the workspace
-// with plain stores, and grad_color_kernel adds up, per source pixel, the slots
-// whose patches cover it, in tile order.  A tap outside the patch (a pose that
+// the lanes arrive.  The rows of the patch that received taps then go to a slot of
+// its own in the workspace with plain stores, and grad_color_kernel adds up, per
+// source pixel, the slots whose touched rectangles cover it, in tile order.  A tap outside the patch (a pose that
 // tears the tile's samples apart) is added to a dense fixed-point image in
 // global memory with an integer atomic instead -- the rare path.
 constexpr int CS_TH = 16, CS_TW = 32, CS_NT = 256;
@@ -1821,17 +1835,23 @@ struct ColorParams {
   const float* invK;
   const float* T;
   const float* gxout;         // [S][B][2][3][H][W]
+  const unsigned char* gany;  // [S][B][H][W]
   unsigned long long* gcol;   // [2][B][3][H][W]   fixed-point sums of the taps outside their patch
   float* slots;               // [B][tiles][2][3][CS_PH][CS_PW]
-  int* anchors;               // [B][tiles][2][2]  (row, column) of patch element (0, 0) in the source image
+  int* anchors;               // [B][tiles][2][4]  (row, column) of patch element (0, 0) in the source image, and the
+                              //                   rectangle of the patch that was touched: rows y0 | y1 << 16,
+                              //                   columns x0 | x1 << 16 (inclusive; y1 < y0 when nothing was)
   unsigned* spill_flag;       // set when any tap went to gcol
 };
 
-// v in 2^-32 units as a two's-complement 64-bit integer, truncated towards zero.  The product
-// v * 2^32 is exact (a power of two) and, for |v| < 2^31, inside the range of the conversion;
-// every contribution, whatever its sign, is off by less than one unit (2^-32).
+// v in 2^-32 units as a two's-complement 64-bit integer, for |v| < 2^31: the integer part and the
+// rest (exact: v - trunc(v)) are converted separately, both towards zero, the rest in steps of 2^-31,
+// so every contribution, whatever its sign, is off by less than 2^-31.  Eight instructions; the
+// compiler's own float -> int64 conversion takes fourteen, twelve times per item.
 __device__ __forceinline__ unsigned long long to_fixed(float v) {
-  return (unsigned long long)(long long)(v * 4294967296.0f);
+  const int hi = (int)v;
+  const int lo = (int)((v - (float)hi) * 2147483648.0f);  // same sign as v, |lo| < 2^31
+  return ((unsigned long long)(unsigned)(hi + (lo >> 31)) << 32) | (unsigned)(lo << 1);
 }
 
 __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorParams p) {
@@ -1842,6 +1862,7 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
   __shared__ int s_anchor[2];
   __shared__ unsigned short s_queue[CS_TH * CS_TW * DW_MAX_SCALES];  // (pixel of the tile << 2) | scale
   __shared__ int s_count;
+  __shared__ int s_rect[4];  // rows and columns of the patch that received a tap: min, max, min, max
   const int tid = threadIdx.x;
   const int ntile = p.tilesX * p.tilesY;
   const int f = blockIdx.x & 1;
@@ -1861,11 +1882,14 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
     const int k = tid - 16;
     s_invK[k] = p.invK[(long)b * 16 + (k / 3) * 4 + (k % 3)];
   }
-  if (tid == 0) s_count = 0;
+  if (tid == 0) {
+    s_count = 0;
+    s_rect[0] = CS_PH, s_rect[1] = -1, s_rect[2] = CS_PW, s_rect[3] = -1;
+  }
   for (int i = tid; i < 3 * CS_PH * CS_PW; i += CS_NT) (&s_patch[0][0])[i] = 0ull;
   // Only pixels that carry a gradient into this frame do any work (elsewhere the adjoint is an
-  // exact zero): they are queued first, for all scales at once, so that the heavy part runs on
-  // full waves and behind a single round of loads.  The order of the queue varies from run to
+  // exact zero; the tile kernel left one byte per pixel and scale saying so): they are queued first,
+  // for all scales at once, so that the heavy part runs on full waves.  The order of the queue varies from run to
   // run; the fixed-point sums do not depend on it.
   const int lane = tid & (kWave - 1);
   {
@@ -1874,14 +1898,13 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
 #pragma unroll
     for (int s = 0; s < DW_MAX_SCALES; ++s) {
       const int sc = s < p.S ? s : 0;
-      const float* gs = p.gxout + ((((long)sc * p.B + b) * 2 + f) * 3) * plane;
+      const unsigned char* gs = p.gany + ((long)sc * p.B + b) * plane;
 #pragma unroll
       for (int it = 0; it < NK; ++it) {
         const int k = tid + it * CS_NT;
         const int y = ty0 + k / CS_TW, x = tx0 + k % CS_TW;
         const bool in_img = y < H && x < W;
-        const float* g = gs + (in_img ? (long)y * W + x : 0);
-        live[s][it] = s < p.S && in_img && (g[0] != 0.f || g[plane] != 0.f || g[2 * plane] != 0.f);
+        live[s][it] = s < p.S && in_img && ((gs[in_img ? (long)y * W + x : 0] >> f) & 1);
       }
     }
     __syncthreads();  // s_count, the patch and the matrices are set
@@ -1927,6 +1950,7 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
   const int oy = s_anchor[0], ox = s_anchor[1];
   const int n_items = s_count;
   bool spilled = false;
+  int y_lo = CS_PH, y_hi = -1, x_lo = CS_PW, x_hi = -1;
 #pragma unroll 1
   for (int i = tid; i < n_items; i += CS_NT) {
     const int item = s_queue[i];
@@ -1943,25 +1967,49 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
     for (int t = 0; t < 4; ++t) {
       const int py = yy[t] - oy, px = xx[t] - ox;
       const bool in = (unsigned)py < (unsigned)CS_PH && (unsigned)px < (unsigned)CS_PW;
+      if (in) {
+        y_lo = min(y_lo, py), y_hi = max(y_hi, py);
+        x_lo = min(x_lo, px), x_hi = max(x_hi, px);
+      }
+      unsigned long long q[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const unsigned long long q = to_fixed(gv[c] * wt[t]);
-        if (in) {
-          __hip_atomic_fetch_add(&s_patch[c][py * CS_PW + px], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-          __hip_atomic_fetch_add(p.gcol + (((long)f * p.B + b) * 3 + c) * plane + (long)yy[t] * W + xx[t], q,
+      for (int c = 0; c < 3; ++c) q[c] = to_fixed(gv[c] * wt[t]);
+      if (in) {  // one branch per tap, not per channel
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          __hip_atomic_fetch_add(&s_patch[c][py * CS_PW + px], q[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          __hip_atomic_fetch_add(p.gcol + (((long)f * p.B + b) * 3 + c) * plane + (long)yy[t] * W + xx[t], q[c],
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          spilled = true;
-        }
+        spilled = true;
       }
     }
   }
   if (spilled) *p.spill_flag = 1u;  // every writer stores the same value
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    y_lo = min(y_lo, __shfl_xor(y_lo, off, kWave)), y_hi = max(y_hi, __shfl_xor(y_hi, off, kWave));
+    x_lo = min(x_lo, __shfl_xor(x_lo, off, kWave)), x_hi = max(x_hi, __shfl_xor(x_hi, off, kWave));
+  }
+  if (lane == 0 && y_hi >= 0) {
+    atomicMin(&s_rect[0], y_lo), atomicMax(&s_rect[1], y_hi);
+    atomicMin(&s_rect[2], x_lo), atomicMax(&s_rect[3], x_hi);
+  }
   __syncthreads();
+  // Only the rows of the patch that received taps go to the slot, whole (a contiguous run per channel: full
+  // cache lines); the reader gets the touched rectangle with the anchor and reads nothing outside it.
+  const int ry0 = s_rect[0], ry1 = s_rect[1], rx0 = s_rect[2], rx1 = s_rect[3];
   float* slot = p.slots + ((long)bt * 2 + f) * (3 * CS_PH * CS_PW);
-  for (int i = tid; i < 3 * CS_PH * CS_PW; i += CS_NT)
-    slot[i] = (float)((double)(long long)(&s_patch[0][0])[i] * (1.0 / 4294967296.0));
-  if (tid < 2) p.anchors[(long)bt * 4 + 2 * f + tid] = s_anchor[tid];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    for (int i = ry0 * CS_PW + tid; i < (ry1 + 1) * CS_PW; i += CS_NT)
+      slot[c * CS_PH * CS_PW + i] = (float)((double)(long long)s_patch[c][i] * (1.0 / 4294967296.0));
+  if (tid < 4) {
+    int* an = p.anchors + ((long)bt * 2 + f) * 4;
+    an[tid] = tid < 2 ? s_anchor[tid] : (tid == 2 ? (ry0 | (ry1 << 16)) : (rx0 | (rx1 << 16)));
+  }
 }
 
 // Fixed-order sum of the slots that cover a source pixel (+ the rare-path image), scaled by the
@@ -1992,15 +2040,17 @@ __global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, 
   for (int tY = tY0; tY <= tY1; ++tY)
     for (int tX = tX0; tX <= tX1; ++tX) {
       const long t = tbase + (long)tY * p.tilesX + tX;
-      const int oy = p.anchors[t * 4 + 2 * f], ox = p.anchors[t * 4 + 2 * f + 1];
-      // does the patch meet the region at all (uniform)?
-      if (oy > y_lo + CS_TH - 1 || oy + CS_PH - 1 < y_lo || ox > x_lo + CS_TW - 1 || ox + CS_PW - 1 < x_lo) continue;
+      const int* an = p.anchors + (t * 2 + f) * 4;
+      const int oy = an[0], ox = an[1];
+      const int ry0 = an[2] & 0xffff, ry1 = an[2] >> 16, rx0 = an[3] & 0xffff, rx1 = an[3] >> 16;
+      // does the touched rectangle of the patch meet the region at all (uniform)?
+      if (oy + ry0 > y_lo + CS_TH - 1 || oy + ry1 < y_lo || ox + rx0 > x_lo + CS_TW - 1 || ox + rx1 < x_lo) continue;
       const int py = y - oy, px = x - ox;
       const float* sl = p.slots + (t * 2 + f) * (3 * CS_PH * CS_PW) + py * CS_PW + px;
-      if ((unsigned)py < (unsigned)CS_PH) {
+      if (py >= ry0 && py <= ry1) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          if ((unsigned)(px + e) < (unsigned)CS_PW) {
+          if (px + e >= rx0 && px + e <= rx1) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[e][c] += sl[c * CS_PH * CS_PW + e];
           }
@@ -2028,7 +2078,7 @@ __global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, 
 struct WsLayout {
   size_t tile_loss, tile_dP, depth_up, gdup, img_scal, sm_img, sm_G, sm_part, total;
   // only with DW_FLAG_COLOR_GRAD: [color_zero_begin, color_zero_end) is cleared by every forward call
-  size_t gxout, slots, anchors, spill_flag, gcol, color_zero_begin, color_zero_end;
+  size_t gxout, gany, slots, anchors, spill_flag, gcol, color_zero_begin, color_zero_end;
   int cX, cY;  // tiles of the colour scatter
 };
 
@@ -2078,15 +2128,17 @@ static void make_layout(const dw_desc& d, ScaleLayout& L, WsLayout& w, TileCount
   o = align_up(o + sizeof(float) * (size_t)d.S * d.B * d.H * d.W, A);
   w.cX = (d.W + CS_TW - 1) / CS_TW;
   w.cY = (d.H + CS_TH - 1) / CS_TH;
-  w.gxout = w.slots = w.anchors = w.spill_flag = w.gcol = w.color_zero_begin = w.color_zero_end = o;
+  w.gxout = w.gany = w.slots = w.anchors = w.spill_flag = w.gcol = w.color_zero_begin = w.color_zero_end = o;
   if (d.flags & DW_FLAG_COLOR_GRAD) {
     const size_t ctiles = (size_t)d.B * w.cX * w.cY;
     w.gxout = o;
     o = align_up(o + sizeof(float) * (size_t)d.S * d.B * 6 * d.H * d.W, A);
+    w.gany = o;
+    o = align_up(o + (size_t)d.S * d.B * d.H * d.W, A);
     w.slots = o;
     o = align_up(o + sizeof(float) * ctiles * 2 * 3 * CS_PH * CS_PW, A);
     w.anchors = o;
-    o = align_up(o + sizeof(int) * ctiles * 4, A);
+    o = align_up(o + sizeof(int) * ctiles * 8, A);
     w.color_zero_begin = w.spill_flag = o;
     o = align_up(o + sizeof(unsigned), A);
     w.gcol = o;
@@ -2205,11 +2257,13 @@ extern "C" int dw_photometric_fwd(const dw_desc* desc, const float* const* disp,
   ColorParams cp{};
   if (cgrad) {
     p.gxout = (float*)(ws + w.gxout);
+    p.gany = (unsigned char*)(ws + w.gany);
     cp.B = p.B, cp.H = p.H, cp.W = p.W, cp.S = p.S;
     cp.tilesX = w.cX, cp.tilesY = w.cY;
     for (int s = 0; s < desc->S; ++s) cp.disp[s] = disp[s];
     cp.K = K, cp.invK = inv_K, cp.T = T;
     cp.gxout = p.gxout;
+    cp.gany = p.gany;
     cp.gcol = (unsigned long long*)(ws + w.gcol);
     cp.slots = (float*)(ws + w.slots);
     cp.anchors = (int*)(ws + w.anchors);
