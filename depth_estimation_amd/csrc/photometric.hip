@@ -2015,8 +2015,8 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
 // Fixed-order sum of the slots that cover a source pixel (+ the rare-path image), scaled by the
 // upstream gradient and the 1 / (S * B * H * W) of the mean.  A block takes one CS_TH x CS_TW
 // region of one source image (two pixels per thread, three channels each) and walks over the
-// tiles whose patch can reach the region -- the same list for every thread, so the anchors are
-// scalar loads and the loop is uniform.
+// tiles whose patch can reach the region -- the same list for every thread, so the loop is uniform.
+constexpr int GC_NU = 2;  // (4 and 8 measured the same)
 __device__ __forceinline__ int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 __global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, const float* __restrict__ grad_loss,
                                                            float inv_count, float* __restrict__ out0,
@@ -2037,25 +2037,61 @@ __global__ __launch_bounds__(CS_NT) void grad_color_kernel(const ColorParams p, 
   const int y = y_lo + ky, x = x_lo + kx;
   float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   const long tbase = (long)b * ntile;
-  for (int tY = tY0; tY <= tY1; ++tY)
-    for (int tX = tX0; tX <= tX1; ++tX) {
-      const long t = tbase + (long)tY * p.tilesX + tX;
-      const int* an = p.anchors + (t * 2 + f) * 4;
-      const int oy = an[0], ox = an[1];
-      const int ry0 = an[2] & 0xffff, ry1 = an[2] >> 16, rx0 = an[3] & 0xffff, rx1 = an[3] >> 16;
-      // does the touched rectangle of the patch meet the region at all (uniform)?
-      if (oy + ry0 > y_lo + CS_TH - 1 || oy + ry1 < y_lo || ox + rx0 > x_lo + CS_TW - 1 || ox + rx1 < x_lo) continue;
-      const int py = y - oy, px = x - ox;
-      const float* sl = p.slots + (t * 2 + f) * (3 * CS_PH * CS_PW) + py * CS_PW + px;
-      if (py >= ry0 && py <= ry1) {
+  // The candidates' records are fetched by one lane each, all at once, and the ones whose touched
+  // rectangle meets the region are then taken in tile order (one dependent load per candidate, one
+  // after the other, was most of this kernel's time).
+  const int lane = threadIdx.x & (kWave - 1);
+  const int ncx = tX1 - tX0 + 1, ncand = (tY1 - tY0 + 1) * ncx;
+  for (int base = 0; base < ncand; base += kWave) {
+    const int i = base + lane;
+    int4 rec = make_int4(0, 0, CS_PH | (-1 << 16), CS_PW | (-1 << 16));  // an empty rectangle
+    long t = 0;
+    if (i < ncand) {
+      t = tbase + (long)(tY0 + i / ncx) * p.tilesX + (tX0 + i % ncx);
+      rec = *reinterpret_cast<const int4*>(p.anchors + (t * 2 + f) * 4);
+    }
+    const bool meets = !((rec.x + (rec.z & 0xffff) > y_lo + CS_TH - 1) || (rec.x + (rec.z >> 16) < y_lo) ||
+                         (rec.y + (rec.w & 0xffff) > x_lo + CS_TW - 1) || (rec.y + (rec.w >> 16) < x_lo));
+    unsigned long long todo = __ballot(meets);
+    while (todo) {
+      // GC_NU tiles per trip: their loads are all in flight before the first is added
+      float v[GC_NU][2][3];
+#pragma unroll
+      for (int u = 0; u < GC_NU; ++u)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          if (px + e >= rx0 && px + e <= rx1) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[e][c] += sl[c * CS_PH * CS_PW + e];
-          }
+          for (int c = 0; c < 3; ++c) v[u][e][c] = 0.f;
+#pragma unroll
+      for (int u = 0; u < GC_NU; ++u) {
+        if (!todo) break;
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int oy = __builtin_amdgcn_readlane(rec.x, k), ox = __builtin_amdgcn_readlane(rec.y, k);
+        const int ry = __builtin_amdgcn_readlane(rec.z, k), rx = __builtin_amdgcn_readlane(rec.w, k);
+        const int ry0 = ry & 0xffff, ry1 = ry >> 16, rx0 = rx & 0xffff, rx1 = rx >> 16;
+        const int ci = base + k;
+        const long tk = tbase + (long)(tY0 + ci / ncx) * p.tilesX + (tX0 + ci % ncx);
+        const int py = y - oy, px = x - ox;
+        const float* sl = p.slots + (tk * 2 + f) * (3 * CS_PH * CS_PW) + py * CS_PW + px;
+        if (py >= ry0 && py <= ry1) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            if (px + e >= rx0 && px + e <= rx1) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) v[u][e][c] = sl[c * CS_PH * CS_PW + e];
+            }
+        }
       }
+      // (a cell outside a tile's rectangle adds an exact zero, which changes no sum)
+#pragma unroll
+      for (int u = 0; u < GC_NU; ++u)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc[e][c] += v[u][e][c];
     }
+  }
   if (y >= p.H) return;
   const bool spill = *p.spill_flag != 0u;
   const float g0 = grad_loss[0] * inv_count;
