@@ -1851,7 +1851,8 @@ struct ColorParams {
 __device__ __forceinline__ unsigned long long to_fixed(float v) {
   const int hi = (int)v;
   const int lo = (int)((v - (float)hi) * 2147483648.0f);  // same sign as v, |lo| < 2^31
-  return ((unsigned long long)(unsigned)(hi + (lo >> 31)) << 32) | (unsigned)(lo << 1);
+  const int carry = lo < 0 ? -1 : 0;  // the upper word of 2 * lo as a 64-bit integer
+  return ((unsigned long long)(unsigned)(hi + carry) << 32) | ((unsigned)lo << 1);
 }
 
 __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorParams p) {
