@@ -149,13 +149,16 @@ def bench_metrics(args):
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
 
-    def fused():
-        assert L.dw_compute_loss_metrics_fwd(B, H, W, H, W, gt.data_ptr(), pred.data_ptr(), 1e-3, 128.0,
-                                             out.data_ptr(), 0, ws.data_ptr(), nb, st) == 0
-        assert L.dw_normalize_image(B, H * W, pred.data_ptr(), out.data_ptr() + 20, 8, img.data_ptr(), None, 0,
-                                    st) == 0
+    def fused():   # two launches: the strip kernel, then the sums and the normalised image
+        assert L.dw_compute_loss_metrics_norm_fwd(B, H, W, H, W, gt.data_ptr(), pred.data_ptr(), 1e-3, 128.0,
+                                                  out.data_ptr(), img.data_ptr(), 0, ws.data_ptr(), nb,
+                                                  torch.cuda.current_stream().cuda_stream) == 0
 
-    ms = timed(fused, args.steps, args.warmup)
+    fused()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fused()
+    ms = min(timed(fused, args.steps, args.warmup), timed(graph.replay, args.steps, args.warmup))
     nbytes = B * H * W * (8 + 8)   # loss+metrics: two maps in; normalize: one in, one out
     o = line("loss_and_metrics", "samples/s", B, ms, args,
              f"compute_loss + rmse + extrema + normalize_image on ({B},1,{H},{W})", "compute_loss_strip_kernel",

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "dw_compute_loss_fwd_static": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, _VP, C.c_int32, _VP]),
     "dw_compute_loss_metrics_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, C.c_float, C.c_float, _VP, C.c_int32,
                                                             _VP, C.c_size_t, _VP]),
+    "dw_compute_loss_metrics_norm_fwd": (C.c_int, [C.c_int32] * 5 + [_VP, _VP, C.c_float, C.c_float, _VP, _VP, C.c_int32,
+                                                   _VP, C.c_size_t, _VP]),
     "dw_normalize_image_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64]),
     "dw_normalize_image": (C.c_int, [C.c_int32, C.c_int64, _VP, _VP, C.c_int32, _VP, _VP, C.c_size_t, _VP]),
     "dw_rmse": (C.c_int, [C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),

@@ -59,6 +59,7 @@ struct ClParams {
   float* part;  // [B][chunks * strips][4 or 8]: sum|dx|, sum|dy|, sum ssim-loss, sum|t - p|,
                 //                                sum (t - clamp(1/p))^2, min p, max p, unused
   float* out;   // [B][4 or 8]
+  float* norm;  // metrics + normalize_image in one call: [B][H * W] receives (pred - min) / (max - min); else null
   float g[4];   // Gaussian taps, centre last (the window is symmetric)
   float clamp_lo, clamp_hi;
 };
@@ -414,7 +415,7 @@ done:
 // PAIR: one block of 512 threads finishes both samples of a pair call, each half exactly as a
 // block of its own would, and then adds the two losses (out[8]).
 template <bool METRICS, bool PAIR>
-__global__ __launch_bounds__(PAIR ? 512 : 256) void compute_loss_finalize_kernel(const ClParams p) {
+__device__ __forceinline__ void compute_loss_finalize_block(const ClParams& p, int sample) {
   constexpr int PS = METRICS ? 8 : 4, NS = METRICS ? 5 : 4;  // partial stride, number of sums
   __shared__ double red_[PAIR ? 2 : 1][NS][256 / kWave];
   __shared__ float ext_[PAIR ? 2 : 1][2][256 / kWave];
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void compute_loss_finalize_kernel
   const int half = PAIR ? threadIdx.x >> 8 : 0;
   double (*red)[256 / kWave] = red_[half];
   float (*ext)[256 / kWave] = ext_[half];
-  const int b = PAIR ? half : blockIdx.x, tid = threadIdx.x & 255, lane = tid & (kWave - 1), wid = tid / kWave;
+  const int b = PAIR ? half : sample, tid = threadIdx.x & 255, lane = tid & (kWave - 1), wid = tid / kWave;
   const int nt = p.strips * p.chunks;
   double a[NS];
   for (int k = 0; k < NS; ++k) a[k] = 0.0;
@@ -482,6 +483,10 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void compute_loss_finalize_kernel
     __syncthreads();
     if (threadIdx.x == 0) p.out[2 * PS] = pair_loss[0] + pair_loss[1];
   }
+}
+template <bool METRICS, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256) void compute_loss_finalize_kernel(const ClParams p) {
+  compute_loss_finalize_block<METRICS, PAIR>(p, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------- normalize_image
@@ -593,6 +598,46 @@ __global__ __launch_bounds__(NI_NT) void normalize_image_kernel(long n, int nblk
   }
 }
 
+// Loss + metrics + normalize_image of the prediction in one call: the launch behind the strip kernel.
+// Block (0, b) finishes sample b's sums as compute_loss_finalize_kernel does; block (1 + k, b) takes the
+// prediction's extrema from the strip kernel's partial results itself (a few hundred floats) and writes
+// chunk k of the normalised image, with the arithmetic of normalize_image_kernel.
+__global__ __launch_bounds__(NI_NT) void compute_loss_finalize_norm_kernel(const ClParams p) {
+  const int b = blockIdx.y;
+  if (blockIdx.x == 0) {
+    compute_loss_finalize_block<true, false>(p, b);
+    return;
+  }
+  __shared__ float red[NI_NT / kWave];
+  __shared__ float s_mm[2];
+  const int nt = p.strips * p.chunks;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int k = threadIdx.x; k < nt; k += NI_NT) {
+    const float* q = p.part + ((long)b * nt + k) * 8;
+    lo = fminf(lo, q[5]);
+    hi = fmaxf(hi, q[6]);
+  }
+  lo = block_extreme<NI_NT, false>(lo, red);
+  hi = block_extreme<NI_NT, true>(hi, red);
+  if (threadIdx.x == 0) {
+    s_mm[0] = lo;
+    s_mm[1] = hi;
+  }
+  __syncthreads();
+  const float mi = s_mm[0], ma = s_mm[1];
+  const float d = (ma != mi) ? (float)((double)ma - (double)mi) : 1e5f;
+  const float inv = 1.0f / d;
+  const long n = (long)p.H * p.W;
+  const float* xb = p.pred + (long)b * n;
+  float* ob = p.norm + (long)b * n;
+  const long base = (long)(blockIdx.x - 1) * NI_PER_BLOCK;
+#pragma unroll 4
+  for (int k = threadIdx.x; k < NI_PER_BLOCK; k += NI_NT) {
+    const long i = base + k;
+    if (i < n) ob[i] = (xb[i] - mi) * inv;
+  }
+}
+
 }  // namespace dw
 
 using namespace dw;
@@ -624,7 +669,7 @@ template <bool METRICS>
 static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
                                const void* target, const float* pred, float clamp_lo, float clamp_hi,
                                float* out, int32_t flags, void* workspace, size_t workspace_bytes, void* stream,
-                               const void* target2 = nullptr, const float* pred2 = nullptr) {
+                               const void* target2 = nullptr, const float* pred2 = nullptr, float* norm = nullptr) {
   if (!target || !pred || !out || !workspace) return DW_ERR_NULL;
   const bool pair = target2 || pred2;
   if (pair && (!target2 || !pred2 || B != 2)) return DW_ERR_ARG;
@@ -654,6 +699,7 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
   p.pred2 = pred2;
   p.part = (float*)workspace;
   p.out = out;
+  p.norm = norm;
   p.clamp_lo = clamp_lo;
   p.clamp_hi = clamp_hi;
   double g[7], sum = 0.0;
@@ -675,10 +721,14 @@ static int compute_loss_launch(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int
     if (mode == 1) compute_loss_strip_kernel<1, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
     if (mode == 2) compute_loss_strip_kernel<2, METRICS, float><<<grid, CL_NT, 0, st>>>(p);
   }
-  if (pair)
+  if (pair) {
     compute_loss_finalize_kernel<METRICS, true><<<1, 512, 0, st>>>(p);
-  else
+  } else if (METRICS && norm) {
+    const long nblk = ((long)H * W + NI_PER_BLOCK - 1) / NI_PER_BLOCK;
+    compute_loss_finalize_norm_kernel<<<dim3((unsigned)(1 + nblk), B), NI_NT, 0, st>>>(p);
+  } else {
     compute_loss_finalize_kernel<METRICS, false><<<B, 256, 0, st>>>(p);
+  }
   return hipGetLastError() == hipSuccess ? DW_OK : DW_ERR_LAUNCH;
 }
 
@@ -705,6 +755,16 @@ extern "C" int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, in
   if (!(clamp_min <= clamp_max)) return DW_ERR_ARG;
   return compute_loss_launch<true>(B, Ht, Wt, H, W, target, pred, clamp_min, clamp_max, out, flags, workspace,
                                    workspace_bytes, stream);
+}
+
+extern "C" int dw_compute_loss_metrics_norm_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                                                const void* target, const float* pred, float clamp_min,
+                                                float clamp_max, float* out, float* pred_normalized, int32_t flags,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!(clamp_min <= clamp_max)) return DW_ERR_ARG;
+  if (!pred_normalized) return DW_ERR_NULL;
+  return compute_loss_launch<true>(B, Ht, Wt, H, W, target, pred, clamp_min, clamp_max, out, flags, workspace,
+                                   workspace_bytes, stream, nullptr, nullptr, pred_normalized);
 }
 
 // ---------------------------------------------------------------- allocation-free entry point

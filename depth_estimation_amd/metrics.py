@@ -69,17 +69,62 @@ def _(target, pred, clamp_min, clamp_max, antialias=False):
     return torch.empty((pred.shape[0], 8), dtype=torch.float32, device=pred.device)
 
 
+@torch.library.custom_op("depthwarp::compute_loss_metrics_norm_fwd", mutates_args=())
+def _loss_metrics_norm(target: Tensor, pred: Tensor, clamp_min: float, clamp_max: float,
+                       antialias: bool = False) -> tuple[Tensor, Tensor]:
+    """As `_loss_metrics`, plus the prediction normalised per sample (`normalize_image`) from the same
+    two launches: -> (B,8), (B,1,H,W)."""
+    _need_cuda(target, pred)
+    if target.dtype not in (torch.float32, torch.float64) or pred.dtype != torch.float32:
+        raise TypeError(f"expected a float32 / float64 target and a float32 prediction, got {target.dtype}, {pred.dtype}")
+    B, _, H, W = pred.shape
+    if target.shape[0] != B:
+        raise RuntimeError("target and pred disagree on the batch size")
+    target, pred = target.contiguous(), pred.contiguous()
+    lib = _lib.lib()
+    nbytes = lib.dw_compute_loss_workspace_bytes(B, H, W)
+    if nbytes == 0:
+        raise _lib.DepthwarpError(f"unsupported shape B={B} H={H} W={W}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+    out = torch.empty((B, 8), dtype=torch.float32, device=pred.device)
+    norm = torch.empty_like(pred)
+    with torch.cuda.device(pred.device):
+        rc = lib.dw_compute_loss_metrics_norm_fwd(B, target.shape[2], target.shape[3], H, W, target.data_ptr(),
+                                                  pred.data_ptr(), clamp_min, clamp_max, out.data_ptr(),
+                                                  norm.data_ptr(),
+                                                  (_lib.DW_CL_FLAG_ANTIALIAS if antialias else 0) |
+                                                  (_lib.DW_CL_FLAG_TARGET_F64 if target.dtype == torch.float64 else 0),
+                                                  ws.data_ptr(), nbytes, _stream(pred))
+    _lib.check(rc, "dw_compute_loss_metrics_norm_fwd")
+    return out, norm
+
+
+@_loss_metrics_norm.register_fake
+def _(target, pred, clamp_min, clamp_max, antialias=False):
+    return (torch.empty((pred.shape[0], 8), dtype=torch.float32, device=pred.device), torch.empty_like(pred))
+
+
 def compute_loss_and_metrics(target: Tensor, pred: Tensor, maxdisp: float = MAXDISP,
-                             antialias: bool = False) -> dict:
+                             antialias: bool = False, normalized: bool = False) -> dict:
     """One pass: dict of (B,) tensors loss, ssim_term, l1, smooth (train.py:272-309),
-    rmse (train.py:311-343, one side) and pred_min / pred_max (train.py:250-251)."""
+    rmse (train.py:311-343, one side) and pred_min / pred_max (train.py:250-251).
+    `normalized=True` adds "pred_normalized" (B,1,H,W) = `normalize_image(pred)` (train.py:248-253),
+    written by the launch that finishes the sums: two launches for everything."""
     with torch.no_grad():
         target = _as_b1hw("target", target)
         if target.dtype not in (torch.float32, torch.float64):
             target = target.float()   # a float64 ground truth (the reference's) is read as it is
-        out = _loss_metrics(target, _as_b1hw("pred", pred).float(), 1e-3, float(maxdisp), antialias)
+        p4 = _as_b1hw("pred", pred).float()
+        norm = None
+        if normalized:
+            out, norm = _loss_metrics_norm(target, p4, 1e-3, float(maxdisp), antialias)
+        else:
+            out = _loss_metrics(target, p4, 1e-3, float(maxdisp), antialias)
     names = ("loss", "ssim_term", "l1", "smooth", "rmse", "pred_min", "pred_max")
-    return {k: out[:, i] for i, k in enumerate(names)}
+    res = {k: out[:, i] for i, k in enumerate(names)}
+    if normalized:
+        res["pred_normalized"] = norm
+    return res
 
 
 def compute_errors(inputs: dict, outputs: dict, maxdisp: float = MAXDISP, antialias: bool = False):

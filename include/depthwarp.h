@@ -239,6 +239,15 @@ DW_API int dw_compute_loss_metrics_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_
                                 float clamp_max, float* out, int32_t flags, void* workspace,
                                 size_t workspace_bytes, void* stream);
 
+/* dw_compute_loss_metrics_fwd and normalize_image of the prediction (train.py:248-253) in one call of two
+ * launches: `pred_normalized` (B, H*W floats) receives (pred - min) / (max - min) per sample, with the
+ * arithmetic of dw_normalize_image (1e5 as the divisor of a constant image), the extrema coming from the
+ * same pass that produces the loss and the metrics.  Everything else as dw_compute_loss_metrics_fwd. */
+DW_API int dw_compute_loss_metrics_norm_fwd(int32_t B, int32_t Ht, int32_t Wt, int32_t H, int32_t W,
+                                     const void* target, const float* pred, float clamp_min,
+                                     float clamp_max, float* out, float* pred_normalized, int32_t flags,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Train.normalize_image, train.py:248-253, per sample and without the two
  * host round trips of the reference: out = (x - min) / (max - min), with 1e5 as
  * the divisor when max == min.

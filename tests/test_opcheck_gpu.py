@@ -33,6 +33,7 @@ def test_loss_and_metric_ops():
     torch.library.opcheck(loss.compute_loss_fwd, (t, p, False), test_utils=TESTS)
     torch.library.opcheck(loss.compute_loss_fwd, (t.double(), p, True), test_utils=TESTS)
     torch.library.opcheck(metrics._loss_metrics, (t, p, 1e-3, 128.0, False), test_utils=TESTS)
+    torch.library.opcheck(metrics._loss_metrics_norm, (t, p, 1e-3, 128.0, False), test_utils=TESTS)
 
 
 def test_disparity_and_cost_volume_ops():
