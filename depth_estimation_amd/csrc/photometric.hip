@@ -1952,39 +1952,72 @@ __global__ __launch_bounds__(CS_NT, 3) void color_scatter_kernel(const ColorPara
   const int n_items = s_count;
   bool spilled = false;
   int y_lo = CS_PH, y_hi = -1, x_lo = CS_PW, x_hi = -1;
+  // CS_NI items per thread and trip, in two phases: every global load of the trip (the adjoint values and
+  // the four disparity taps of each item; the taps of scale 0 are the pixel itself with weights 1 and 0,
+  // the same value bit for bit) is issued before the first is used.
+#ifndef CS_NI
+#define CS_NI 2
+#endif
 #pragma unroll 1
-  for (int i = tid; i < n_items; i += CS_NT) {
-    const int item = s_queue[i];
-    const int k = item >> 2, s = item & 3;
-    const int y = ty0 + k / CS_TW, x = tx0 + k % CS_TW;
-    const float* g = p.gxout + ((((long)s * p.B + b) * 2 + f) * 3) * plane + (long)y * W + x;
-    const float gv[3] = {g[0], g[plane], g[2 * plane]};
-    SampleAddr a;
-    sample_at(s, y, x, a);
-    const float ex = 1.0f - a.tx, ey = 1.0f - a.ty;
-    const float wt[4] = {ex * ey, a.tx * ey, ex * a.ty, a.tx * a.ty};
-    const int yy[4] = {a.y0, a.y0, a.y1, a.y1}, xx[4] = {a.x0, a.x1, a.x0, a.x1};
+  for (int i = tid; i < n_items; i += CS_NI * CS_NT) {
+    bool on[CS_NI];
+    int ys[CS_NI], xs[CS_NI];
+    float gv[CS_NI][3], v4[CS_NI][4], lx[CS_NI][2], ly[CS_NI][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int py = yy[t] - oy, px = xx[t] - ox;
-      const bool in = (unsigned)py < (unsigned)CS_PH && (unsigned)px < (unsigned)CS_PW;
-      if (in) {
-        y_lo = min(y_lo, py), y_hi = max(y_hi, py);
-        x_lo = min(x_lo, px), x_hi = max(x_hi, px);
-      }
-      unsigned long long q[3];
+    for (int u = 0; u < CS_NI; ++u) {
+      on[u] = i + u * CS_NT < n_items;
+      const int item = s_queue[on[u] ? i + u * CS_NT : i];
+      const int k = item >> 2, sc = item & 3;
+      const int y = ty0 + k / CS_TW, x = tx0 + k % CS_TW;
+      ys[u] = y, xs[u] = x;
+      const float* g = p.gxout + ((((long)sc * p.B + b) * 2 + f) * 3) * plane + (long)y * W + x;
+      gv[u][0] = g[0], gv[u][1] = g[plane], gv[u][2] = g[2 * plane];
+      const int hs = H >> sc, ws = W >> sc;
+      const float* d = p.disp[sc] + (long)b * hs * ws;
+      const Taps ty = upsample_taps(y, hs, (float)hs / (float)H), tx = upsample_taps(x, ws, (float)ws / (float)W);
+      v4[u][0] = d[(long)ty.i0 * ws + tx.i0], v4[u][1] = d[(long)ty.i0 * ws + tx.i1];
+      v4[u][2] = d[(long)ty.i1 * ws + tx.i0], v4[u][3] = d[(long)ty.i1 * ws + tx.i1];
+      lx[u][0] = tx.l0, lx[u][1] = tx.l1, ly[u][0] = ty.l0, ly[u][1] = ty.l1;
+    }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) q[c] = to_fixed(gv[c] * wt[t]);
-      if (in) {  // one branch per tap, not per channel
+    for (int u = 0; u < CS_NI; ++u) {
+      const float top = lx[u][0] * v4[u][0] + lx[u][1] * v4[u][1];
+      const float bot = lx[u][0] * v4[u][2] + lx[u][1] * v4[u][3];
+      const float du = ly[u][0] * top + ly[u][1] * bot;
+      const float dsp = kMinDisp + kDispRange * du;
+      const float depth = div_by(1.0f, dsp, div_rcp(dsp));
+      const float fx = (float)xs[u], fy = (float)ys[u];
+      const float X = depth * ((s_invK[0] * fx + s_invK[1] * fy) + s_invK[2]);
+      const float Y = depth * ((s_invK[3] * fx + s_invK[4] * fy) + s_invK[5]);
+      const float Z = depth * ((s_invK[6] * fx + s_invK[7] * fy) + s_invK[8]);
+      SampleAddr a;
+      sample_addr<false>(H, W, dc, s_P, X, Y, Z, (unsigned)f, a);
+      const float ex = 1.0f - a.tx, ey = 1.0f - a.ty;
+      const float wt[4] = {ex * ey, a.tx * ey, ex * a.ty, a.tx * a.ty};
+      const int yy[4] = {a.y0, a.y0, a.y1, a.y1}, xx[4] = {a.x0, a.x1, a.x0, a.x1};
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          __hip_atomic_fetch_add(&s_patch[c][py * CS_PW + px], q[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
+      for (int t = 0; t < 4; ++t) {
+        const int py = yy[t] - oy, px = xx[t] - ox;
+        const bool in = (unsigned)py < (unsigned)CS_PH && (unsigned)px < (unsigned)CS_PW;
+        if (in && on[u]) {
+          y_lo = min(y_lo, py), y_hi = max(y_hi, py);
+          x_lo = min(x_lo, px), x_hi = max(x_hi, px);
+        }
+        unsigned long long q[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          __hip_atomic_fetch_add(p.gcol + (((long)f * p.B + b) * 3 + c) * plane + (long)yy[t] * W + xx[t], q[c],
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        spilled = true;
+        for (int c = 0; c < 3; ++c) q[c] = to_fixed(gv[u][c] * wt[t]);
+        if (!on[u]) continue;
+        if (in) {  // one branch per tap, not per channel
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            __hip_atomic_fetch_add(&s_patch[c][py * CS_PW + px], q[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            __hip_atomic_fetch_add(p.gcol + (((long)f * p.B + b) * 3 + c) * plane + (long)yy[t] * W + xx[t], q[c],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          spilled = true;
+        }
       }
     }
   }
