@@ -17,4 +17,14 @@ for flags in (0, 4):
     e0.record()
     for _ in range(50): step()
     e1.record(); torch.cuda.synchronize()
-    print(f"flags={flags}: {e0.elapsed_time(e1) / 50:.4f} ms/step (eager launches)")
+    eager = e0.elapsed_time(e1) / 50
+    # the same step replayed from a HIP graph (what bench.py times when it is the faster of the two)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(5): graph.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50): graph.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"flags={flags}: {eager:.4f} ms/step (eager launches), {e0.elapsed_time(e1) / 50:.4f} ms/step (graph replay)")
